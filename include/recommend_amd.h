@@ -1,0 +1,239 @@
+/*
+ * recommend_amd.h -- C ABI of librecommend_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the data-parallel hot path of the multi-modal graph
+ * recommender: bipartite-graph propagation (CSR/CSC SpMM, forward/backward),
+ * BPR gather-dot loss with negative sampling, and full-ranking evaluation
+ * (score, train-mask, top-K, ranking metrics).
+ *
+ * The reference is pure Python and has no FFI of its own; every entry point
+ * below names the reference function (file:line under the reference tree)
+ * whose arithmetic it replaces.  The Python host classes in recommend_amd/
+ * keep the reference's call protocols and bind these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no framework types cross this boundary;
+ *  - every function returns RK_OK (0) or a negative RK_ERR_* code and never
+ *    throws; rk_last_error() returns a thread-local message for the last
+ *    failure on the calling thread;
+ *  - pointers named *_host are host memory, everything else is device memory
+ *    owned by the caller; the library allocates no device memory;
+ *  - `stream` is a hipStream_t passed as void*; all device work is enqueued
+ *    asynchronously on it and the functions do not synchronise;
+ *  - dense matrices are row-major fp32, 16-byte aligned rows; graph indices
+ *    are int32 on the device (node count and nnz < 2^31); batch ids are
+ *    int64 as the reference's batch dict holds them.
+ */
+#ifndef RECOMMEND_AMD_H
+#define RECOMMEND_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_OK 0
+#define RK_ERR_ARG (-1)         /* bad pointer / size / unsupported shape   */
+#define RK_ERR_HIP (-2)         /* a HIP runtime call or launch failed      */
+#define RK_ERR_UNSUPPORTED (-3) /* valid request outside the built kernels  */
+#define RK_ERR_NODEV (-4)       /* no gfx950 device visible                 */
+
+#define RK_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------- */
+int rk_abi_version(void);
+const char *rk_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only host, never an error) */
+int rk_device_count(void);
+
+/* ---- G1: edge list and CSR/CSC construction (host, bit-exact) ---------- */
+/* Replaces GraphConstructor.build_graph, model/test/graph_constructor.py:51-117
+ * (edge order :80-98).  For interaction j (dataset order) emits edge 2j
+ * (u -> i+U) and edge 2j+1 (i+U -> u), both with weight rating[j]; then, if
+ * add_self_loops, edge 2E+n (n -> n) for n = 0..N-1 with weight
+ * max(0, max_j rating[j]).  nnz = 2E (+N).  ratings_host may be NULL (all 1). */
+int rk_build_coo_host(const int64_t *users_host, const int64_t *items_host,
+                      const float *ratings_host, int64_t n_inter,
+                      int32_t n_users, int32_t n_items, int32_t add_self_loops,
+                      int32_t *src_host, int32_t *dst_host, float *w_host);
+
+/* Stable counting sort of the COO by `key` (dst for the forward CSR, src for
+ * the transposed/CSC form used by the backward pass), ties by edge id.
+ * ptr has n_nodes+1 entries; idx[p] = other[eid[p]]; eid[p] = COO edge id.
+ * This ordering is the bit-exact CSR contract (dgl.graph + update_all read the
+ * same COO, graph_constructor.py:101-105). */
+int rk_csr_from_coo_host(const int32_t *key_host, const int32_t *other_host,
+                         int64_t nnz, int32_t n_nodes, int32_t *ptr_host,
+                         int32_t *idx_host, int32_t *eid_host);
+
+/* Row binning for the SpMM kernels: rows longer than long_thresh are cut into
+ * chunks of `chunk` edges.  First call with the output pointers NULL to get
+ * the counts, then with buffers of n_long, n_long+1, n_chunks, n_chunks. */
+int rk_spmm_plan_host(const int32_t *ptr_host, int32_t n_rows,
+                      int32_t long_thresh, int32_t chunk, int32_t *n_long_out,
+                      int32_t *n_chunks_out, int32_t *long_rows_host,
+                      int32_t *long_chunk_ptr_host, int32_t *chunk_begin_host,
+                      int32_t *chunk_end_host);
+
+/* ---- G2: symmetric normalisation (device) ------------------------------ */
+/* Replaces GraphConstructor._normalize_graph/_norm, graph_constructor.py:158-187:
+ * in_w[v] = sum over incoming edges of w (edge-id order), clamp(min=1e-12),
+ * sqrt, then w_e <- w_e / (in_w[src_e] * in_w[dst_e]).  Inputs: forward CSR
+ * (rows = dst) with its eid permutation and the COO-ordered raw weights.
+ * Outputs: sqrt_in_w[n_nodes] and the COO-ordered normalised weights. */
+int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
+                         const int32_t *eid, const float *w_coo,
+                         int32_t n_nodes, float *sqrt_in_w, float *w_norm_coo,
+                         void *stream);
+
+/* Degree normalisation of the live models (model/sgrec/graph.py:123-135,
+ * model/mig/mgdcf.py:106-126): w_e = deg_in[src]^-0.5 * deg_in[dst]^-0.5 with
+ * deg_in counted from the CSR (rows = dst). */
+int rk_deg_normalize_f32(const int32_t *rowptr, const int32_t *col,
+                         const int32_t *eid, int32_t n_nodes,
+                         float *w_norm_coo, void *stream);
+
+/* out[p] = src[idx[p]] (permutes COO-ordered edge values into CSR/CSC order) */
+int rk_gather_f32(const float *src, const int32_t *idx, int64_t n, float *out,
+                  void *stream);
+
+/* ---- G3: propagation h <- A h (device) ---------------------------------- */
+typedef struct rk_spmm_plan {
+  int32_t long_thresh;            /* rows with more edges are "long"        */
+  int32_t n_long;                 /* number of long rows                    */
+  const int32_t *long_rows;       /* [n_long] row ids                       */
+  const int32_t *long_chunk_ptr;  /* [n_long+1] chunk range of each long row */
+  int32_t n_chunks;
+  const int32_t *chunk_begin;     /* [n_chunks] first edge of the chunk     */
+  const int32_t *chunk_end;       /* [n_chunks] one past its last edge      */
+  float *partial;                 /* [n_chunks * D] scratch, caller-owned   */
+} rk_spmm_plan;
+
+/* Replaces update_all(fn.u_mul_e('h','weight','m'), fn.sum('m','h')),
+ * graph_constructor.py:194,205 (also model/sgrec/gcn.py:84, model/mig/mgdcf.py:152):
+ *   out[v,:] = sum_{p in row v} val[p] * h[col[p],:]
+ * and, when h0 != NULL, the fused epilogue of aggrate (graph_constructor.py:195)
+ * and MGDCF (mgdcf.py:152-153):  out = alpha*h0 + beta*(A h).
+ * The backward pass is the same call on the CSC arrays (d h = A^T d out).
+ * plan may be NULL (every row handled by one lane group).  D % 4 == 0. */
+int rk_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
+                    int32_t n_rows, const float *h, int32_t D, float *out,
+                    const float *h0, float alpha, float beta,
+                    const rk_spmm_plan *plan, void *stream);
+
+/* ---- W1: modality projection (device, fp32 MFMA) ------------------------ */
+/* Replaces nn.Linear(feat_dim, emb_dim) applied to the zero-padded feature
+ * matrix, model/Main_Model.py:65-74,154: user rows of the padded input are all
+ * zero, so Y[u,:] = b for u < n_users and Y[n_users+i,:] = X[i,:] W^T + b.
+ * X: n_items x F, W: D x F (nn.Linear layout), b: D or NULL, Y: (U+I) x D. */
+int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W,
+                    const float *b, int32_t D, int32_t n_users, float *Y,
+                    void *stream);
+size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F,
+                            int32_t D);
+/* dW = dY[item rows]^T X (D x F), db = column sums of dY over all U+I rows.
+ * ws must hold rk_proj_bwd_ws_bytes() bytes.  db may be NULL. */
+int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
+                    int32_t D, int32_t n_users, float *dW, float *db, void *ws,
+                    size_t ws_bytes, void *stream);
+
+/* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
+/* Replaces GraphDataLoader._generate_negative_samples,
+ * data/graph_data_loader.py:355-397, whose random.sample / random.choices calls
+ * draw from CPython's process-global MT19937.  state is 625 words (624 + index).
+ * rk_mt_seed follows random.seed(int) for 0 <= seed < 2^64. */
+int rk_mt_seed_host(uint32_t *state625_host, uint64_t seed);
+/* One batch: for each user in order, n = n_items - |pos(u)| candidates in
+ * ascending id order; draws R ranks exactly as random.sample(cands, R) does
+ * (random.choices when n < R) and writes the ranks and/or the resolved item
+ * ids (either output may be NULL).  pos_ptr/pos_items: per-user sorted, unique
+ * positives over the full interaction table (CSR, host). */
+int rk_neg_sample_host(uint32_t *state625_host, const int64_t *users_host,
+                       int64_t B, int32_t R, const int32_t *pos_ptr_host,
+                       const int32_t *pos_items_host, int32_t n_items,
+                       int32_t *rank_out_host, int64_t *neg_out_host);
+
+/* ---- L1: BPR gather-dot loss (device) ----------------------------------- */
+/* Replaces GraphTrainer._loss_func, train/graph_trainer.py:255-270, and
+ * bpr_loss, evalue/loss.py:7-28:
+ *   x[b,r] = <U[u_b], I[i_b]> - <U[u_b], I[n_{b,r}]>
+ *   loss = mean(-logsigmoid(x))            (mask == NULL)
+ *        = sum(-logsigmoid(x)*m)/max(sum m,1)   (mask != NULL)
+ * If neg_rank != NULL the negatives are resolved inside the kernel as the
+ * rank-th smallest item id not in pos(u) (device CSR pos_ptr/pos_items) and
+ * written to neg (the sampling of graph_data_loader.py:378-387 with the host
+ * RNG ranks from rk_neg_sample_host); otherwise neg is an input.
+ * x_out: B*R saved differences for the backward pass.
+ * loss_out[0] = loss, loss_out[1] = denominator used.
+ * ws: at least rk_bpr_ws_bytes(B, R) bytes of scratch. */
+size_t rk_bpr_ws_bytes(int64_t B, int32_t R);
+int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
+                   const int64_t *users, const int64_t *pos, int64_t *neg,
+                   int64_t B, int32_t R, const float *mask,
+                   const int32_t *neg_rank, const int32_t *pos_ptr,
+                   const int32_t *pos_items, int32_t n_items, float *x_out,
+                   float *loss_out, void *ws, size_t ws_bytes, void *stream);
+/* Gradient of the loss above w.r.t. U and I rows, scaled by *gout (device
+ * scalar), accumulated with float atomics into dU/dI (caller zero-fills). */
+int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
+                   const int64_t *users, const int64_t *pos, const int64_t *neg,
+                   int64_t B, int32_t R, const float *mask, const float *x,
+                   const float *loss_out, const float *gout, float *dU,
+                   float *dI, void *stream);
+
+/* Score-level form: bpr_loss(pos_scores[B], neg_scores[B,R], mask),
+ * evalue/loss.py:7-28, for callers that computed the scores themselves.
+ * ws as rk_bpr_ws_bytes(B, R). */
+int rk_bpr_scores_fwd_f32(const float *pos, const float *neg, int64_t B,
+                          int32_t R, const float *mask, float *x_out,
+                          float *loss_out, void *ws, size_t ws_bytes,
+                          void *stream);
+int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
+                          const float *loss_out, const float *gout, int64_t B,
+                          int32_t R, float *dpos, float *dneg, void *stream);
+
+/* ---- E1: fused score + train-mask + top-K (device, fp32 MFMA) ----------- */
+/* Replaces torch.matmul(U, I.T); S[row_id, col_id] = -1e10; torch.topk(S, k),
+ * evalue/evaluator.py:54-55,98-99 and evalue/metric.py:114, without writing S.
+ * Score of (u,i) is the fp32 fma chain over the embedding index in the order
+ * 0,32,1,33,...,31,63 within each block of 64 (D % 64 == 0), starting from 0.
+ * Ranking: score descending, ties by lower item id.  mask_ptr/mask_items: CSR of
+ * the training interactions per user (items ascending, local to this item
+ * range), may be NULL.  Item ids written are local index + item_id_offset.
+ * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 32). */
+size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D,
+                              int32_t K);
+int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb,
+                      int32_t n_items, int32_t D, const int32_t *mask_ptr,
+                      const int32_t *mask_items, int32_t K,
+                      int32_t item_id_offset, float *out_scores,
+                      int32_t *out_ids, void *ws, size_t ws_bytes,
+                      void *stream);
+/* Merge P candidate lists per user (each Kin long, any order, padding entries
+ * have id < 0) into the best K by (score desc, id asc).  Used for the item
+ * splits inside one GPU and for the all-gathered per-GPU lists. */
+int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users,
+                      int32_t P, int32_t Kin, int32_t K, float *out_scores,
+                      int32_t *out_ids, void *stream);
+
+/* ---- M: ranking metrics (device) ---------------------------------------- */
+/* Replaces evaluate_all_at_k, evalue/metric.py:106-164, for every k in k_list
+ * at once from one sorted top-Kmax id list per user and the CSR of the target
+ * (validation/test) items per user (sorted).  discounts[j] = 1/log2(j+2).
+ * out[ki*6 + m], m = precision, recall, hit_rate, ndcg, map, mrr: means over
+ * all n_users rows.  sums_out (may be NULL): the same as double sums before
+ * the division (for cross-GPU reduction).  ws: rk_rank_metrics_ws_bytes(). */
+size_t rk_rank_metrics_ws_bytes(int32_t n_users, int32_t nk);
+int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users,
+                        int32_t id_stride, const int32_t *tgt_ptr,
+                        const int32_t *tgt_items, const int32_t *k_list_host,
+                        int32_t nk, const float *discounts, float *out,
+                        double *sums_out, int64_t mean_denominator, void *ws,
+                        size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECOMMEND_AMD_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of librecommend_amd.so (the C ABI in include/recommend_amd.h).
+
+Only plain pointers and sizes cross the boundary.  Tensors are passed as
+``tensor.data_ptr()``; the caller keeps them alive until the stream has run.
+There is no CPU implementation behind these calls: if the library is missing,
+or a device entry point is used without a GPU, the call raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32,
+                    c_int64, c_size_t, c_uint32, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librecommend_amd.so")
+
+RK_OK = 0
+RK_ERR_ARG = -1
+RK_ERR_HIP = -2
+RK_ERR_UNSUPPORTED = -3
+RK_ERR_NODEV = -4
+
+
+class RkError(RuntimeError):
+    """A librecommend_amd call returned a negative code."""
+
+    def __init__(self, code, message):
+        super().__init__(f"librecommend_amd error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class SpmmPlan(Structure):
+    _fields_ = [
+        ("long_thresh", c_int32),
+        ("n_long", c_int32),
+        ("long_rows", c_void_p),
+        ("long_chunk_ptr", c_void_p),
+        ("n_chunks", c_int32),
+        ("chunk_begin", c_void_p),
+        ("chunk_end", c_void_p),
+        ("partial", c_void_p),
+    ]
+
+
+P = c_void_p
+# name -> (restype, argtypes); mirrors include/recommend_amd.h declaration by declaration
+SIGNATURES = {
+    "rk_abi_version": (c_int32, []),
+    "rk_last_error": (c_char_p, []),
+    "rk_device_count": (c_int32, []),
+    "rk_build_coo_host": (c_int32, [P, P, P, c_int64, c_int32, c_int32, c_int32, P, P, P]),
+    "rk_csr_from_coo_host": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
+    "rk_spmm_plan_host": (c_int32, [P, c_int32, c_int32, c_int32, POINTER(c_int32),
+                                    POINTER(c_int32), P, P, P, P]),
+    "rk_sym_normalize_f32": (c_int32, [P, P, P, P, c_int32, P, P, P]),
+    "rk_deg_normalize_f32": (c_int32, [P, P, P, c_int32, P, P]),
+    "rk_gather_f32": (c_int32, [P, P, c_int64, P, P]),
+    "rk_spmm_csr_f32": (c_int32, [P, P, P, c_int32, P, c_int32, P, P, c_float, c_float,
+                                  POINTER(SpmmPlan), P]),
+    "rk_proj_fwd_f32": (c_int32, [P, c_int32, c_int32, P, P, c_int32, c_int32, P, P]),
+    "rk_proj_bwd_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "rk_proj_bwd_f32": (c_int32, [P, c_int32, c_int32, P, c_int32, c_int32, P, P, P, c_size_t, P]),
+    "rk_mt_seed_host": (c_int32, [P, c_uint64]),
+    "rk_neg_sample_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P]),
+    "rk_bpr_ws_bytes": (c_size_t, [c_int64, c_int32]),
+    "rk_bpr_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32,
+                                 P, P, P, c_size_t, P]),
+    "rk_bpr_bwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, P, P, P]),
+    "rk_bpr_scores_fwd_f32": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, c_size_t, P]),
+    "rk_bpr_scores_bwd_f32": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, P]),
+    "rk_score_topk_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "rk_score_topk_f32": (c_int32, [P, c_int32, P, c_int32, c_int32, P, P, c_int32, c_int32,
+                                    P, P, P, c_size_t, P]),
+    "rk_topk_merge_f32": (c_int32, [P, P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
+    "rk_rank_metrics_ws_bytes": (c_size_t, [c_int32, c_int32]),
+    "rk_rank_metrics_f32": (c_int32, [P, c_int32, c_int32, P, P, P, c_int32, P, P, P, c_int64,
+                                      P, c_size_t, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RkError(RK_ERR_NODEV, f"{LIB_PATH} is missing: run `python -m recommend_amd.build` "
+                      "(or __graft_entry__.build()) first; there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rk_abi_version() != 1:
+        raise RkError(RK_ERR_UNSUPPORTED, "librecommend_amd ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().rk_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(code):
+    if code != RK_OK:
+        raise RkError(code, last_error())
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise RkError on failure."""
+    check(getattr(load(), name)(*args))
+
+
+def device_count():
+    return int(load().rk_device_count())
+
+
+def require_device():
+    """Device entry points need a GPU; fail loudly instead of computing elsewhere."""
+    if device_count() < 1:
+        raise RkError(RK_ERR_NODEV, "no HIP device visible: the recommend_amd device path "
+                      "runs only on a GPU and has no CPU fallback")
+
+
+def ptr(t):
+    """Device or host address of a tensor / numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return c_void_p(t.data_ptr())
+    return c_void_p(t.ctypes.data)
+
+
+def stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+__all__ = ["load", "call", "check", "ptr", "stream_ptr", "SpmmPlan", "RkError", "SIGNATURES",
+           "LIB_PATH", "device_count", "require_device", "last_error",
+           "c_int32", "c_int64", "c_float", "c_double", "c_uint32", "c_size_t"]

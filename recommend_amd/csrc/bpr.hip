@@ -1,0 +1,296 @@
+// BPR gather-dot loss, forward and backward, with the negative-item lookup
+// folded into the forward kernel (gfx950).
+//
+// One group of 16 lanes owns one training sample; every lane walks the
+// embedding row in float4 steps (stride 16 float4), so D = 64 is exactly one
+// coalesced 256-byte read per gathered row.  The per-sample losses are reduced
+// in a fixed order (group -> block -> final block), never with float atomics,
+// so the forward value is run-to-run deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int GL = 16;           // lanes per sample
+constexpr int SPB = 256 / GL;    // samples per block
+
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = GL / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, GL);
+  return v;
+}
+
+__device__ __forceinline__ float dot_rows(const float4 *__restrict__ a,
+                                          const float4 *__restrict__ b, int d4,
+                                          int sub) {
+  float s = 0.0f;
+  for (int q = sub; q < d4; q += GL) {
+    const float4 x = a[q], y = b[q];
+    s = fmaf(x.x, y.x, s);
+    s = fmaf(x.y, y.y, s);
+    s = fmaf(x.z, y.z, s);
+    s = fmaf(x.w, y.w, s);
+  }
+  return group_sum(s);
+}
+
+// rank-th smallest id not in the sorted list pos[0..len)
+__device__ __forceinline__ int64_t kth_missing(const int32_t *__restrict__ pos,
+                                               int32_t len, int32_t rank) {
+  int32_t lo = 0, hi = len;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (pos[mid] - mid <= rank)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return (int64_t)rank + lo;
+}
+
+// -logsigmoid(x) = max(-x, 0) + log1p(exp(-|x|))
+__device__ __forceinline__ float neg_logsigmoid(float x) {
+  return fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void bpr_fwd_kernel(
+    const float *__restrict__ U, const float *__restrict__ I, int32_t D,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    int64_t *__restrict__ neg, int64_t B, int32_t R,
+    const float *__restrict__ mask, const int32_t *__restrict__ neg_rank,
+    const int32_t *__restrict__ pos_ptr, const int32_t *__restrict__ pos_items,
+    float *__restrict__ x_out, float *__restrict__ part) {
+  __shared__ float s_loss[SPB], s_den[SPB];
+  const int sub = threadIdx.x % GL, grp = threadIdx.x / GL;
+  const int64_t s = (int64_t)blockIdx.x * SPB + grp;
+  const int d4 = D / 4;
+  float loss = 0.0f, den = 0.0f;
+  if (s < B) {
+    const int64_t u = users[s];
+    const float4 *pu = reinterpret_cast<const float4 *>(U + u * D);
+    const float4 *pi = reinterpret_cast<const float4 *>(I + pos[s] * D);
+    const float ps = dot_rows(pu, pi, d4, sub);
+    for (int32_t r = 0; r < R; ++r) {
+      int64_t n;
+      if (neg_rank) {
+        const int32_t rank = neg_rank[s * R + r];
+        // rank < 0: the "no candidate" dummy item 0 (graph_data_loader.py:383)
+        n = rank < 0 ? 0
+                     : kth_missing(pos_items + pos_ptr[u], pos_ptr[u + 1] - pos_ptr[u], rank);
+        if (sub == 0) neg[s * R + r] = n;
+      } else {
+        n = neg[s * R + r];
+      }
+      const float4 *ni = reinterpret_cast<const float4 *>(I + n * D);
+      const float x = ps - dot_rows(pu, ni, d4, sub);
+      const float m = mask ? mask[s * R + r] : 1.0f;
+      if (sub == 0) x_out[s * R + r] = x;
+      loss += neg_logsigmoid(x) * m;
+      den += m;
+    }
+  }
+  if (sub == 0) {
+    s_loss[grp] = loss;
+    s_den[grp] = den;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.0f, d = 0.0f;
+    for (int g = 0; g < SPB; ++g) {
+      l += s_loss[g];
+      d += s_den[g];
+    }
+    part[2 * blockIdx.x] = l;
+    part[2 * blockIdx.x + 1] = d;
+  }
+}
+
+__global__ void bpr_final_kernel(const float *__restrict__ part, int32_t n_part,
+                                 int use_mask, float *__restrict__ loss_out) {
+  // one wavefront, fixed order: lane strides, then a shuffle tree
+  float l = 0.0f, d = 0.0f;
+  for (int32_t i = threadIdx.x; i < n_part; i += rk::kWave) {
+    l += part[2 * i];
+    d += part[2 * i + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    l += __shfl_xor(l, off, rk::kWave);
+    d += __shfl_xor(d, off, rk::kWave);
+  }
+  if (threadIdx.x == 0) {
+    // bpr_loss: loss.mean()  |  loss.sum() / mask.sum().clamp_min(1.0)
+    const float denom = use_mask ? fmaxf(d, 1.0f) : d;
+    loss_out[0] = l / denom;
+    loss_out[1] = denom;
+  }
+}
+
+__device__ __forceinline__ void atomic_axpy(float *__restrict__ dst,
+                                            const float4 *__restrict__ src,
+                                            float a, int d4, int sub) {
+  for (int q = sub; q < d4; q += GL) {
+    const float4 v = src[q];
+    atomicAdd(dst + 4 * q + 0, a * v.x);
+    atomicAdd(dst + 4 * q + 1, a * v.y);
+    atomicAdd(dst + 4 * q + 2, a * v.z);
+    atomicAdd(dst + 4 * q + 3, a * v.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void bpr_bwd_kernel(
+    const float *__restrict__ U, const float *__restrict__ I, int32_t D,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    const int64_t *__restrict__ neg, int64_t B, int32_t R,
+    const float *__restrict__ mask, const float *__restrict__ x,
+    const float *__restrict__ loss_out, const float *__restrict__ gout,
+    float *__restrict__ dU, float *__restrict__ dI) {
+  const int sub = threadIdx.x % GL;
+  const int64_t s = (int64_t)blockIdx.x * SPB + threadIdx.x / GL;
+  if (s >= B) return;
+  const int d4 = D / 4;
+  const float scale = gout[0] / loss_out[1];
+  const int64_t u = users[s], p = pos[s];
+  const float4 *pu = reinterpret_cast<const float4 *>(U + u * D);
+  const float4 *pi = reinterpret_cast<const float4 *>(I + p * D);
+  float gsum = 0.0f;
+  for (int32_t r = 0; r < R; ++r) {
+    const float xv = x[s * R + r];
+    const float m = mask ? mask[s * R + r] : 1.0f;
+    // d(-logsigmoid(x))/dx = -sigmoid(-x) = -1/(1+exp(x))
+    const float g = -scale * m / (1.0f + expf(xv));
+    const int64_t n = neg[s * R + r];
+    const float4 *ni = reinterpret_cast<const float4 *>(I + n * D);
+    // x = <pu,pi> - <pu,ni>:  d/dni = -g*pu ; d/dpu += g*(pi - ni)
+    atomic_axpy(dI + n * D, pu, -g, d4, sub);
+    atomic_axpy(dU + u * D, ni, -g, d4, sub);
+    gsum += g;
+  }
+  atomic_axpy(dI + p * D, pu, gsum, d4, sub);
+  atomic_axpy(dU + u * D, pi, gsum, d4, sub);
+}
+
+// score-level form of the same loss (bpr_loss called on precomputed scores)
+__global__ __launch_bounds__(256) void bpr_scores_fwd_kernel(
+    const float *__restrict__ pos, const float *__restrict__ neg, int64_t B, int32_t R,
+    const float *__restrict__ mask, float *__restrict__ x_out, float *__restrict__ part) {
+  __shared__ float s_loss[4], s_den[4];
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.0f, den = 0.0f;
+  if (s < B) {
+    const float ps = pos[s];
+    for (int32_t r = 0; r < R; ++r) {
+      const float x = ps - neg[s * R + r];
+      const float m = mask ? mask[s * R + r] : 1.0f;
+      x_out[s * R + r] = x;
+      loss += neg_logsigmoid(x) * m;
+      den += m;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_xor(loss, off, rk::kWave);
+    den += __shfl_xor(den, off, rk::kWave);
+  }
+  if (threadIdx.x % rk::kWave == 0) {
+    s_loss[threadIdx.x / rk::kWave] = loss;
+    s_den[threadIdx.x / rk::kWave] = den;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = ((s_loss[0] + s_loss[1]) + s_loss[2]) + s_loss[3];
+    part[2 * blockIdx.x + 1] = ((s_den[0] + s_den[1]) + s_den[2]) + s_den[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void bpr_scores_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ mask,
+    const float *__restrict__ loss_out, const float *__restrict__ gout, int64_t B, int32_t R,
+    float *__restrict__ dpos, float *__restrict__ dneg) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= B) return;
+  const float scale = gout[0] / loss_out[1];
+  float gsum = 0.0f;
+  for (int32_t r = 0; r < R; ++r) {
+    const float m = mask ? mask[s * R + r] : 1.0f;
+    const float g = -scale * m / (1.0f + expf(x[s * R + r]));
+    dneg[s * R + r] = -g;
+    gsum += g;
+  }
+  dpos[s] = gsum;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_bpr_scores_fwd_f32(const float *pos, const float *neg, int64_t B, int32_t R,
+                          const float *mask, float *x_out, float *loss_out, void *ws,
+                          size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(B > 0 && R > 0, "empty score tensors");
+  RK_CHECK_ARG(pos && neg && x_out && loss_out && ws, "null pointer");
+  const int32_t nb = (int32_t)rk::ceil_div(B, 256);
+  RK_CHECK_ARG(ws_bytes >= (size_t)(2 * nb) * sizeof(float), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  bpr_scores_fwd_kernel<<<nb, 256, 0, st>>>(pos, neg, B, R, mask, x_out, (float *)ws);
+  RK_CHECK_LAUNCH("bpr_scores_fwd_kernel");
+  bpr_final_kernel<<<1, rk::kWave, 0, st>>>((const float *)ws, nb, mask != nullptr, loss_out);
+  RK_CHECK_LAUNCH("bpr_final_kernel");
+  return RK_OK;
+}
+
+int rk_bpr_scores_bwd_f32(const float *x, const float *mask, const float *loss_out,
+                          const float *gout, int64_t B, int32_t R, float *dpos, float *dneg,
+                          void *stream) {
+  RK_CHECK_ARG(B > 0 && R > 0, "empty score tensors");
+  RK_CHECK_ARG(x && loss_out && gout && dpos && dneg, "null pointer");
+  bpr_scores_bwd_kernel<<<(int32_t)rk::ceil_div(B, 256), 256, 0, (hipStream_t)stream>>>(
+      x, mask, loss_out, gout, B, R, dpos, dneg);
+  RK_CHECK_LAUNCH("bpr_scores_bwd_kernel");
+  return RK_OK;
+}
+
+size_t rk_bpr_ws_bytes(int64_t B, int32_t R) {
+  (void)R;
+  if (B < 0) return 0;
+  return (size_t)(2 * rk::ceil_div(B, SPB) + 2) * sizeof(float);
+}
+
+int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
+                   const int64_t *users, const int64_t *pos, int64_t *neg,
+                   int64_t B, int32_t R, const float *mask,
+                   const int32_t *neg_rank, const int32_t *pos_ptr,
+                   const int32_t *pos_items, int32_t n_items, float *x_out,
+                   float *loss_out, void *ws, size_t ws_bytes, void *stream) {
+  // train/graph_trainer.py:262-263 raises on an empty batch
+  RK_CHECK_ARG(B > 0 && R > 0, "batch error, recive null user or item or neg_items");
+  RK_CHECK_ARG(U && I && users && pos && neg && x_out && loss_out && ws, "null pointer");
+  RK_CHECK_ARG(D > 0 && D % 4 == 0, "embedding width must be a multiple of 4");
+  RK_CHECK_ARG(rk::aligned16(U) && rk::aligned16(I), "embeddings must be 16-byte aligned");
+  RK_CHECK_ARG(ws_bytes >= rk_bpr_ws_bytes(B, R), "workspace too small");
+  if (neg_rank) RK_CHECK_ARG(pos_ptr && pos_items && n_items > 0, "sampling needs the user->positives CSR");
+  hipStream_t st = (hipStream_t)stream;
+  const int32_t nb = (int32_t)rk::ceil_div(B, SPB);
+  float *part = (float *)ws;
+  bpr_fwd_kernel<<<nb, 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask, neg_rank, pos_ptr,
+                                      pos_items, x_out, part);
+  RK_CHECK_LAUNCH("bpr_fwd_kernel");
+  bpr_final_kernel<<<1, rk::kWave, 0, st>>>(part, nb, mask != nullptr, loss_out);
+  RK_CHECK_LAUNCH("bpr_final_kernel");
+  return RK_OK;
+}
+
+int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
+                   const int64_t *users, const int64_t *pos, const int64_t *neg,
+                   int64_t B, int32_t R, const float *mask, const float *x,
+                   const float *loss_out, const float *gout, float *dU,
+                   float *dI, void *stream) {
+  RK_CHECK_ARG(B > 0 && R > 0, "empty batch");
+  RK_CHECK_ARG(U && I && users && pos && neg && x && loss_out && gout && dU && dI, "null pointer");
+  RK_CHECK_ARG(D > 0 && D % 4 == 0, "embedding width must be a multiple of 4");
+  bpr_bwd_kernel<<<(int32_t)rk::ceil_div(B, SPB), 256, 0, (hipStream_t)stream>>>(
+      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, dU, dI);
+  RK_CHECK_LAUNCH("bpr_bwd_kernel");
+  return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,486 @@
+// Full-ranking evaluation: fused score (fp32 MFMA) + train-mask + per-lane
+// top-K that never writes the user x item score matrix, a list merge, and the
+// ranking-metric reductions (gfx950).
+//
+// score_topk_kernel.  A workgroup of 4 wavefronts owns 128 users and one slice
+// of the item range.  Item rows are staged 32 at a time through a
+// double-buffered, padded LDS tile shared by the 4 wavefronts; each wavefront
+// multiplies the tile with its 32 users on v_mfma_f32_32x32x2_f32.  With the
+// items on the MFMA rows and the users on the MFMA columns, lane l ends up
+// with 16 scores that all belong to user (l & 31): the whole top-K state of a
+// user lives in two lanes' registers (a sorted list of KPAD scores and ids)
+// and no cross-lane traffic is needed while streaming.  A score enters a lane's
+// list only if it beats the lane's current KPAD-th best, which is rare after
+// the first tiles, so candidates are parked in a small per-lane LDS queue and
+// the (expensive, fully unrolled) sorted insertion runs only when some lane's
+// queue is nearly full, with all lanes inserting together.
+//
+// Because every lane sees its items in ascending id order and insertion uses a
+// strict '>', equal scores keep the lower item id first; the final merge of
+// the per-lane / per-slice lists orders by (score desc, id asc) explicitly.
+#include "common.h"
+
+namespace {
+
+using rk::kWave;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int TI = 32;     // items per LDS tile (MFMA rows)
+constexpr int UPB = 128;   // users per workgroup (4 wavefronts x 32)
+constexpr int QS = 8;      // queue slots per lane
+constexpr int ROWPAD = 4;  // floats of padding per LDS tile row (bank spread)
+constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
+
+__host__ __device__ inline int kpad_for(int K) { return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
+
+// number of item slices per user tile: enough workgroups to fill 256 CUs a few
+// times over, a power of two so that slices map onto XCDs (blockIdx % 8)
+inline int choose_nsplit(int n_users, int n_items) {
+  const int utiles = (int)rk::ceil_div(n_users, UPB);
+  const int tiles = (int)rk::ceil_div(n_items, TI);
+  int ns = 1;
+  while (utiles * ns < 2048 && ns < 64 && tiles / (ns * 2) >= 4) ns *= 2;
+  return ns;
+}
+
+template <int KPAD>
+struct LaneList {
+  float s[KPAD];
+  int32_t id[KPAD];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) {
+      s[j] = -INFINITY;
+      id[j] = -1;
+    }
+  }
+  // sorted insertion; a no-op for lanes whose v does not beat the last entry
+  __device__ __forceinline__ void insert(float v, int32_t vid) {
+    bool c_hi = v > s[KPAD - 1];
+#pragma unroll
+    for (int j = KPAD - 1; j >= 1; --j) {
+      const bool c_lo = v > s[j - 1];
+      s[j] = c_lo ? s[j - 1] : (c_hi ? v : s[j]);
+      id[j] = c_lo ? id[j - 1] : (c_hi ? vid : id[j]);
+      c_hi = c_lo;
+    }
+    s[0] = c_hi ? v : s[0];
+    id[0] = c_hi ? vid : id[0];
+  }
+};
+
+template <int KPAD, int DC>
+__global__ __launch_bounds__(256) void score_topk_kernel(
+    const float *__restrict__ Uemb, int32_t n_users,
+    const float *__restrict__ Iemb, int32_t n_items,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
+    int32_t nsplit, int32_t item_id_offset, float *__restrict__ part_s,
+    int32_t *__restrict__ part_id) {
+  constexpr int D = 64 * DC;
+  constexpr int ROW = D + ROWPAD;
+  __shared__ __attribute__((aligned(16))) float tile[2][TI * ROW];
+  __shared__ float q_s[4][QS][kWave];
+  __shared__ int32_t q_id[4][QS][kWave];
+
+  const int tid = threadIdx.x;
+  const int wave = tid / kWave, lane = tid % kWave;
+  const int col = lane & 31, half = lane >> 5;
+  const int32_t split = blockIdx.x % nsplit;
+  const int32_t utile = blockIdx.x / nsplit;
+  const int32_t user = utile * UPB + wave * 32 + col;
+  const bool user_ok = user < n_users;
+
+  const int32_t tiles_total = (n_items + TI - 1) / TI;
+  const int32_t t_lo = (int32_t)((int64_t)tiles_total * split / nsplit);
+  const int32_t t_hi = (int32_t)((int64_t)tiles_total * (split + 1) / nsplit);
+
+  // user fragment: B[k][j=col], this lane holds k = 64c + 32*half + m
+  float bfrag[DC][32];
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (user_ok)
+        v = *reinterpret_cast<const float4 *>(Uemb + (int64_t)user * D + 64 * c + 32 * half + 4 * q);
+      bfrag[c][4 * q + 0] = v.x;
+      bfrag[c][4 * q + 1] = v.y;
+      bfrag[c][4 * q + 2] = v.z;
+      bfrag[c][4 * q + 3] = v.w;
+    }
+
+  // train-mask cursor of this lane's user (item ids ascending)
+  int32_t mcur = 0, mend = 0;
+  if (mask_ptr && user_ok) {
+    mcur = mask_ptr[user];
+    mend = mask_ptr[user + 1];
+    // skip entries in front of this slice
+    int32_t lo = mcur, hi = mend;
+    const int32_t first = t_lo * TI;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (mask_items[mid] < first)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    mcur = lo;
+  }
+  int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+
+  LaneList<KPAD> list;
+  list.init();
+  float thr = -INFINITY;
+  int qc = 0;
+
+  // tile staging: 32 rows x D floats = 8*DC float4 per row, 2*DC float4 per thread
+  constexpr int F4_PER_ROW = D / 4;
+  constexpr int LOADS = TI * F4_PER_ROW / 256;
+  float4 stage[LOADS];
+  auto load_tile = [&](int32_t t) {
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int e = tid + 256 * j;
+      const int32_t item = t * TI + e / F4_PER_ROW;
+      stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (item < n_items)
+        stage[j] = *reinterpret_cast<const float4 *>(Iemb + (int64_t)item * D + 4 * (e % F4_PER_ROW));
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<float4 *>(&tile[buf][(e / F4_PER_ROW) * ROW + 4 * (e % F4_PER_ROW)]) = stage[j];
+    }
+  };
+  auto flush = [&]() {
+#pragma unroll 1
+    for (int q = 0; q < QS; ++q) {
+      const bool has = q < qc;
+      if (!__any(has)) break;
+      const float v = has ? q_s[wave][q][lane] : -INFINITY;
+      const int32_t vid = q_id[wave][q][lane];
+      list.insert(v, vid);
+    }
+    qc = 0;
+    thr = list.s[KPAD - 1];
+  };
+
+  if (t_lo < t_hi) {
+    load_tile(t_lo);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int32_t t = t_lo; t < t_hi; ++t) {
+    const int buf = (t - t_lo) & 1;
+    if (t + 1 < t_hi) load_tile(t + 1);
+
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      float afrag[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 v =
+            *reinterpret_cast<const float4 *>(&tile[buf][col * ROW + 64 * c + 32 * half + 4 * q]);
+        afrag[4 * q + 0] = v.x;
+        afrag[4 * q + 1] = v.y;
+        afrag[4 * q + 2] = v.z;
+        afrag[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfrag[c][m], acc, 0, 0, 0);
+    }
+
+    const int32_t item0 = t * TI;
+    // rows past the end of the item table never rank
+    if (item0 + TI > n_items) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (item0 + (r & 3) + 8 * (r >> 2) + 4 * half >= n_items) acc[r] = -INFINITY;
+    }
+    // training interactions of this user inside the tile get the mask score
+    if (__any(next_m < item0 + TI)) {
+      uint32_t mbits = 0;
+      while (next_m < item0 + TI) {
+        const int32_t rel = next_m - item0;
+        if (((rel >> 2) & 1) == half) mbits |= 1u << (((rel >> 3) << 2) | (rel & 3));
+        ++mcur;
+        next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((mbits >> r) & 1u) acc[r] = kMasked;
+    }
+    // park candidates; insert when a queue could overflow in the next 4 steps
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[r];
+      if (v > thr) {
+        q_s[wave][qc][lane] = v;
+        q_id[wave][qc][lane] = item0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        ++qc;
+      }
+      if ((r & 3) == 3) {
+        if (__any(qc > QS - 4)) flush();
+      }
+    }
+
+    if (t + 1 < t_hi) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  flush();
+
+  if (user_ok) {
+    const int32_t P = 2 * nsplit;
+    const int64_t base = ((int64_t)user * P + split * 2 + half) * KPAD;
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) {
+      part_s[base + j] = list.s[j];
+      part_id[base + j] = list.id[j] < 0 ? -1 : list.id[j] + item_id_offset;
+    }
+  }
+}
+
+// One wavefront per user ranks all n = P*Kin candidates by counting how many
+// beat each one; candidates with rank < K are written to their final slot.
+constexpr int MERGE_MAX = 1024;
+
+__device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, int32_t ib, int jb) {
+  const bool va = ia >= 0, vb = ib >= 0;
+  if (va != vb) return va;
+  if (!va) return ja < jb;
+  return sa > sb || (sa == sb && (ia < ib || (ia == ib && ja < jb)));
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(
+    const float *__restrict__ scores, const int32_t *__restrict__ ids,
+    int32_t n_users, int32_t n, int32_t K, float *__restrict__ out_s,
+    int32_t *__restrict__ out_id) {
+  __shared__ float cs[4][MERGE_MAX];
+  __shared__ int32_t ci[4][MERGE_MAX];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int32_t user = blockIdx.x * 4 + wave;
+  if (user >= n_users) return;  // wave-uniform; no block barrier below
+  for (int c = lane; c < n; c += kWave) {
+    cs[wave][c] = scores[(int64_t)user * n + c];
+    ci[wave][c] = ids[(int64_t)user * n + c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
+  for (int c = lane; c < n; c += kWave) {
+    const float sc = cs[wave][c];
+    const int32_t ic = ci[wave][c];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += beats(cs[wave][j], ci[wave][j], j, sc, ic, c) ? 1 : 0;
+    if (rank < K) {
+      out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
+      out_id[(int64_t)user * K + rank] = ic;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- M -------
+constexpr int MAXK = 8;  // k values per call
+
+struct KList {
+  int32_t k[MAXK];
+};
+
+__global__ __launch_bounds__(256) void rank_metrics_kernel(
+    const int32_t *__restrict__ topk_ids, int32_t n_users, int32_t id_stride,
+    const int32_t *__restrict__ tgt_ptr, const int32_t *__restrict__ tgt_items,
+    KList kl, int32_t nk, int32_t kmax, const float *__restrict__ disc,
+    double *__restrict__ part) {
+  __shared__ double red[4][MAXK * 6];
+  const int32_t u = blockIdx.x * 256 + threadIdx.x;
+  float vals[MAXK * 6];
+#pragma unroll
+  for (int i = 0; i < MAXK * 6; ++i) vals[i] = 0.0f;
+  if (u < n_users) {
+    const int32_t tb = tgt_ptr[u], te = tgt_ptr[u + 1];
+    const int32_t n_pos = te - tb;
+    uint32_t rel = 0;  // bit j: j-th ranked item is a target item
+    for (int j = 0; j < kmax; ++j) {
+      const int32_t it = topk_ids[(int64_t)u * id_stride + j];
+      int32_t lo = tb, hi = te;
+      while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (tgt_items[mid] < it)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (it >= 0 && lo < te && tgt_items[lo] == it) rel |= 1u << j;
+    }
+    // evalue/metric.py:119-155, per user, fp32
+    const float positives = (float)max(n_pos, 1);
+#pragma unroll
+    for (int ki = 0; ki < MAXK; ++ki) {
+      if (ki < nk) {
+        const int k = kl.k[ki];
+        float hits = 0.f, dcg = 0.f, idcg = 0.f, ap = 0.f, cum = 0.f;
+        int first = 0;
+        const int ideal_k = min(n_pos, k);
+        for (int j = 0; j < k; ++j) {
+          const float rj = (float)((rel >> j) & 1u);
+          hits += rj;
+          dcg += rj * disc[j];
+          if (j < ideal_k) idcg += disc[j];
+          cum += rj;
+          ap += (cum / (float)(j + 1)) * rj;
+          if (rj != 0.f && first == 0) first = j + 1;
+        }
+        vals[ki * 6 + 0] = hits / (float)k;
+        vals[ki * 6 + 1] = hits / positives;
+        vals[ki * 6 + 2] = hits > 0.f ? 1.f : 0.f;
+        vals[ki * 6 + 3] = idcg > 0.f ? dcg / idcg : 0.f;
+        vals[ki * 6 + 4] = ap / positives;
+        vals[ki * 6 + 5] = first > 0 ? 1.0f / (float)first : 0.f;
+      }
+    }
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int i = 0; i < MAXK * 6; ++i) {
+    double v = (double)vals[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXK * 6)
+    part[(int64_t)blockIdx.x * (MAXK * 6) + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void rank_metrics_final_kernel(const double *__restrict__ part, int32_t n_part,
+                                          int32_t nk, double denom, float *__restrict__ out,
+                                          double *__restrict__ sums_out) {
+  const int i = threadIdx.x;  // one thread per (k, metric), sequential over blocks
+  if (i >= nk * 6) return;
+  double s = 0.0;
+  for (int32_t b = 0; b < n_part; ++b) s += part[(int64_t)b * (MAXK * 6) + i];
+  if (sums_out) sums_out[i] = s;
+  out[i] = (float)(s / denom);
+}
+
+template <int KPAD>
+int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32_t n_users,
+                      const float *Iemb, int32_t n_items, const int32_t *mask_ptr,
+                      const int32_t *mask_items, int32_t nsplit, int32_t off, float *ps,
+                      int32_t *pi) {
+  switch (DC) {
+    case 1:
+      score_topk_kernel<KPAD, 1><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
+                                                        mask_items, nsplit, off, ps, pi);
+      break;
+    case 2:
+      score_topk_kernel<KPAD, 2><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
+                                                        mask_items, nsplit, off, ps, pi);
+      break;
+    default:
+      return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)",
+                      64 * DC);
+  }
+  RK_CHECK_LAUNCH("score_topk_kernel");
+  return RK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
+  (void)D;
+  if (n_users <= 0 || n_items <= 0 || K <= 0 || K > 32) return 0;
+  const int nsplit = choose_nsplit(n_users, n_items);
+  return (size_t)n_users * 2 * nsplit * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
+}
+
+int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, int32_t P,
+                      int32_t Kin, int32_t K, float *out_scores, int32_t *out_ids, void *stream) {
+  RK_CHECK_ARG(n_users >= 0 && P > 0 && Kin > 0 && K > 0, "bad sizes");
+  if (n_users == 0) return RK_OK;
+  RK_CHECK_ARG(scores && ids && out_scores && out_ids, "null pointer");
+  RK_CHECK_ARG((int64_t)P * Kin <= MERGE_MAX, "too many candidates per user (%lld > %d)",
+               (long long)P * Kin, MERGE_MAX);
+  RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
+  topk_merge_kernel<<<(int)rk::ceil_div(n_users, 4), 256, 0, (hipStream_t)stream>>>(
+      scores, ids, n_users, P * Kin, K, out_scores, out_ids);
+  RK_CHECK_LAUNCH("topk_merge_kernel");
+  return RK_OK;
+}
+
+int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
+                      int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
+                      int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
+                      size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(n_users > 0 && n_items > 0, "empty score matrix");
+  // evalue/metric.py:9-10
+  RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
+  if (K > 32) return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above the built maximum 32", K);
+  RK_CHECK_ARG(D > 0 && D % 64 == 0, "embedding width must be a multiple of 64");
+  RK_CHECK_ARG(Uemb && Iemb && out_scores && out_ids && ws, "null pointer");
+  RK_CHECK_ARG((mask_ptr == nullptr) == (mask_items == nullptr), "mask_ptr and mask_items go together");
+  RK_CHECK_ARG(rk::aligned16(Uemb) && rk::aligned16(Iemb), "embeddings must be 16-byte aligned");
+  RK_CHECK_ARG(ws_bytes >= rk_score_topk_ws_bytes(n_users, n_items, D, K), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = choose_nsplit(n_users, n_items);
+  const int kp = kpad_for(K);
+  const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
+  float *ps = (float *)ws;
+  int32_t *pi = (int32_t *)(ps + (size_t)n_users * 2 * nsplit * kp);
+  int rc;
+  switch (kp) {
+    case 8: rc = launch_score_topk<8>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    case 16: rc = launch_score_topk<16>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    case 24: rc = launch_score_topk<24>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    default: rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+  }
+  if (rc != RK_OK) return rc;
+  return rk_topk_merge_f32(ps, pi, n_users, 2 * nsplit, kp, K, out_scores, out_ids, stream);
+}
+
+size_t rk_rank_metrics_ws_bytes(int32_t n_users, int32_t nk) {
+  (void)nk;
+  if (n_users < 0) return 0;
+  return (size_t)(rk::ceil_div(n_users, 256) + 1) * MAXK * 6 * sizeof(double);
+}
+
+int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_stride,
+                        const int32_t *tgt_ptr, const int32_t *tgt_items,
+                        const int32_t *k_list_host, int32_t nk, const float *discounts,
+                        float *out, double *sums_out, int64_t mean_denominator, void *ws,
+                        size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(n_users > 0 && nk > 0 && nk <= MAXK, "need 1..%d k values and at least one user", MAXK);
+  RK_CHECK_ARG(topk_ids && tgt_ptr && tgt_items && k_list_host && discounts && out && ws, "null pointer");
+  RK_CHECK_ARG(ws_bytes >= rk_rank_metrics_ws_bytes(n_users, nk), "workspace too small");
+  RK_CHECK_ARG(mean_denominator > 0, "mean denominator must be positive");
+  KList kl;
+  int kmax = 0;
+  for (int i = 0; i < MAXK; ++i) {
+    kl.k[i] = i < nk ? k_list_host[i] : 0;
+    if (i < nk) {
+      RK_CHECK_ARG(kl.k[i] >= 1 && kl.k[i] <= 32 && kl.k[i] <= id_stride,
+                   "k=%d outside [1, min(32, id_stride)]", kl.k[i]);
+      if (kl.k[i] > kmax) kmax = kl.k[i];
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)rk::ceil_div(n_users, 256);
+  rank_metrics_kernel<<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk,
+                                           kmax, discounts, (double *)ws);
+  RK_CHECK_LAUNCH("rank_metrics_kernel");
+  rank_metrics_final_kernel<<<1, 64, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
+                                               out, sums_out);
+  RK_CHECK_LAUNCH("rank_metrics_final_kernel");
+  return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+// Modality projection Y = [b ; X W^T + b] and its weight/bias gradients on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// The reference pads the item feature matrix with one all-zero row per user
+// and runs nn.Linear over all U+I rows; a zero row times W is exactly zero, so
+// the user rows of the output are the bias and only the I item rows need a
+// GEMM.  Forward: 128 x 64 output tile per workgroup (4 wavefronts x 32 rows),
+// K streamed 32 columns at a time through double-buffered, padded LDS tiles.
+// Backward: dW = dY_items^T X is a GEMM whose reduction runs over the items;
+// it is cut into item slices whose 64 x 128 partial tiles are summed in slice
+// order by a second kernel (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+
+using rk::kWave;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int LDA = BK + 4;  // padded LDS row (floats): conflict-free b128 reads
+
+__global__ __launch_bounds__(256) void proj_fill_users_kernel(const float *__restrict__ b, int32_t D,
+                                                              int64_t n, float *__restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) Y[i] = b ? b[i % D] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void proj_fwd_kernel(const float *__restrict__ X, int32_t n_items,
+                                                       int32_t F, const float *__restrict__ W,
+                                                       const float *__restrict__ b, int32_t D,
+                                                       float *__restrict__ Yitems) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDA];
+  const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+  const int col = lane & 31, half = lane >> 5;
+  const int32_t m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  float4 sa[4], sb[2];
+  auto load = [&](int32_t k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j, r = e >> 3, c = (e & 7) * 4;
+      sa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < n_items && k0 + c < F)
+        sa[j] = *reinterpret_cast<const float4 *>(X + (int64_t)(m0 + r) * F + k0 + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + 256 * j, r = e >> 3, c = (e & 7) * 4;
+      sb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + r < D && k0 + c < F)
+        sb[j] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + r) * F + k0 + c);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<float4 *>(&As[buf][(e >> 3) * LDA + (e & 7) * 4]) = sa[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<float4 *>(&Bs[buf][(e >> 3) * LDA + (e & 7) * 4]) = sb[j];
+    }
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int32_t nk = (F + BK - 1) / BK;
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int32_t kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load((kt + 1) * BK);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // lane half h takes columns 8j+4h .. 8j+4h+3 of the K tile
+      const float4 a = *reinterpret_cast<const float4 *>(&As[buf][(wave * 32 + col) * LDA + 8 * j + 4 * half]);
+      const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[buf][col * LDA + 8 * j + 4 * half]);
+      const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[buf][(32 + col) * LDA + 8 * j + 4 * half]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store(buf ^ 1);
+    __syncthreads();
+  }
+  // C layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int32_t n = n0 + 32 * t + col;
+    if (n >= D) continue;
+    const float bias = b ? b[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int32_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < n_items) Yitems[(int64_t)m * D + n] = acc[t][r] + bias;
+    }
+  }
+}
+
+// dW partial: workgroup (f-tile, d-tile, slice) reduces items [i_lo, i_hi).
+// A[i = d][k = item] = dY[item][d], B[k = item][j = f] = X[item][f].
+constexpr int WF = 128;  // f columns per workgroup (4 wavefronts x 32)
+constexpr int WI = 32;   // items per LDS step
+
+__global__ __launch_bounds__(256) void proj_dw_kernel(const float *__restrict__ X, int32_t n_items,
+                                                      int32_t F, const float *__restrict__ dYitems,
+                                                      int32_t D, int32_t items_per_slice,
+                                                      float *__restrict__ slab) {
+  __shared__ __attribute__((aligned(16))) float Ys[2][WI * 64];
+  __shared__ __attribute__((aligned(16))) float Xs[2][WI * WF];
+  const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+  const int col = lane & 31, half = lane >> 5;
+  const int32_t f0 = blockIdx.x * WF, d0 = blockIdx.y * 64;
+  const int32_t i_lo = blockIdx.z * items_per_slice;
+  const int32_t i_hi = min(i_lo + items_per_slice, n_items);
+
+  float4 sy[2], sx[4];
+  auto load = [&](int32_t i0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // 32 x 64 floats = 512 float4
+      const int e = tid + 256 * j, r = e >> 4, c = (e & 15) * 4;
+      sy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + r < i_hi && d0 + c < D)
+        sy[j] = *reinterpret_cast<const float4 *>(dYitems + (int64_t)(i0 + r) * D + d0 + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // 32 x 128 floats = 1024 float4
+      const int e = tid + 256 * j, r = e >> 5, c = (e & 31) * 4;
+      sx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + r < i_hi && f0 + c < F)
+        sx[j] = *reinterpret_cast<const float4 *>(X + (int64_t)(i0 + r) * F + f0 + c);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<float4 *>(&Ys[buf][(e >> 4) * 64 + (e & 15) * 4]) = sy[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + 256 * j;
+      *reinterpret_cast<float4 *>(&Xs[buf][(e >> 5) * WF + (e & 31) * 4]) = sx[j];
+    }
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const int32_t steps = (i_hi - i_lo + WI - 1) / WI;
+  if (steps > 0) {
+    load(i_lo);
+    store(0);
+  }
+  __syncthreads();
+  for (int32_t s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < steps) load(i_lo + (s + 1) * WI);
+#pragma unroll
+    for (int kk = 0; kk < WI; kk += 2) {
+      const float bx = Xs[buf][(kk + half) * WF + wave * 32 + col];
+      const float a0 = Ys[buf][(kk + half) * 64 + col];
+      const float a1 = Ys[buf][(kk + half) * 64 + 32 + col];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bx, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bx, acc[1], 0, 0, 0);
+    }
+    if (s + 1 < steps) store(buf ^ 1);
+    __syncthreads();
+  }
+  // slab[slice][d][f]
+  float *out = slab + (int64_t)blockIdx.z * D * F;
+  const int32_t f = f0 + wave * 32 + col;
+  if (f < F) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int32_t d = d0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (d < D) out[(int64_t)d * F + f] = acc[t][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
+                                                          int32_t n_slices, int64_t n,
+                                                          float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int32_t k = 0; k < n_slices; ++k) s += slab[(int64_t)k * n + i];
+  out[i] = s;
+}
+
+// column sums of a rows x D matrix: stage 1 sums row blocks, stage 2 = slab_reduce
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ M, int64_t rows,
+                                                     int32_t D, float *__restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
+  for (int32_t c = threadIdx.x; c < D; c += 256) {
+    float s = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) s += M[r * D + c];
+    part[(int64_t)blockIdx.x * D + c] = s;
+  }
+}
+
+inline int dw_slices(int32_t n_items, int32_t F, int32_t D) {
+  const int64_t tiles = rk::ceil_div(F, WF) * rk::ceil_div(D, 64);
+  int64_t s = rk::ceil_div(1024, tiles);
+  const int64_t max_s = std::max<int64_t>(1, n_items / 256);
+  if (s > max_s) s = max_s;
+  return (int)std::max<int64_t>(1, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, const float *b,
+                    int32_t D, int32_t n_users, float *Y, void *stream) {
+  RK_CHECK_ARG(n_items >= 0 && n_users >= 0 && F > 0 && D > 0, "bad sizes");
+  RK_CHECK_ARG(F % 4 == 0 && D % 4 == 0, "feature and embedding widths must be multiples of 4");
+  RK_CHECK_ARG(W && Y && (n_items == 0 || X), "null pointer");
+  RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(Y), "matrices must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nu = (int64_t)n_users * D;
+  if (nu > 0) {
+    proj_fill_users_kernel<<<(unsigned)rk::ceil_div(nu, 256), 256, 0, st>>>(b, D, nu, Y);
+    RK_CHECK_LAUNCH("proj_fill_users_kernel");
+  }
+  if (n_items > 0) {
+    dim3 grid((unsigned)rk::ceil_div(n_items, BM), (unsigned)rk::ceil_div(D, BN));
+    proj_fwd_kernel<<<grid, 256, 0, st>>>(X, n_items, F, W, b, D, Y + nu);
+    RK_CHECK_LAUNCH("proj_fwd_kernel");
+  }
+  return RK_OK;
+}
+
+size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F, int32_t D) {
+  if (n_items < 0 || n_users < 0 || F <= 0 || D <= 0) return 0;
+  // dW slabs; the bias partials reuse the same buffer afterwards
+  const size_t slab = (size_t)dw_slices(n_items, F, D) * D * F * sizeof(float);
+  const size_t bias = (size_t)rk::ceil_div((int64_t)n_items + n_users, CS_ROWS) * D * sizeof(float);
+  return slab > bias ? slab : bias;
+}
+
+int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY, int32_t D,
+                    int32_t n_users, float *dW, float *db, void *ws, size_t ws_bytes,
+                    void *stream) {
+  RK_CHECK_ARG(n_items >= 0 && n_users >= 0 && F > 0 && D > 0, "bad sizes");
+  RK_CHECK_ARG(F % 4 == 0 && D % 4 == 0, "feature and embedding widths must be multiples of 4");
+  RK_CHECK_ARG(dY && dW && ws && (n_items == 0 || X), "null pointer");
+  RK_CHECK_ARG(ws_bytes >= rk_proj_bwd_ws_bytes(n_items, n_users, F, D), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nW = (int64_t)D * F;
+  const int slices = dw_slices(n_items, F, D);
+  float *slab = (float *)ws;
+  if (n_items > 0) {
+    const int32_t ips = (int32_t)(rk::ceil_div(rk::ceil_div(n_items, slices), WI) * WI);
+    dim3 grid((unsigned)rk::ceil_div(F, WF), (unsigned)rk::ceil_div(D, 64), (unsigned)slices);
+    proj_dw_kernel<<<grid, 256, 0, st>>>(X, n_items, F, dY + (int64_t)n_users * D, D, ips, slab);
+    RK_CHECK_LAUNCH("proj_dw_kernel");
+    slab_reduce_kernel<<<(unsigned)rk::ceil_div(nW, 256), 256, 0, st>>>(slab, slices, nW, dW);
+    RK_CHECK_LAUNCH("slab_reduce_kernel");
+  } else {
+    RK_CHECK_HIP(hipMemsetAsync(dW, 0, nW * sizeof(float), st));
+  }
+  if (db) {
+    const int64_t rows = (int64_t)n_users + n_items;
+    const int64_t nb = rk::ceil_div(rows, CS_ROWS);
+    if (nb == 0) {
+      RK_CHECK_HIP(hipMemsetAsync(db, 0, D * sizeof(float), st));
+    } else {
+      colsum_kernel<<<(unsigned)nb, 256, 0, st>>>(dY, rows, D, slab);
+      RK_CHECK_LAUNCH("colsum_kernel");
+      slab_reduce_kernel<<<(unsigned)rk::ceil_div(D, 256), 256, 0, st>>>(slab, (int32_t)nb, D, db);
+      RK_CHECK_LAUNCH("slab_reduce_kernel");
+    }
+  }
+  return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+"""Tensor-level wrappers of the C ABI: autograd Functions for the propagation,
+projection and BPR kernels, plain functions for evaluation.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; all
+arithmetic of the hot path runs in librecommend_amd.so.  Every function here
+requires CUDA(HIP) tensors and raises otherwise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import c_float, c_int32, c_int64, c_size_t, ptr, stream_ptr
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _ffi.RkError(_ffi.RK_ERR_NODEV,
+                               "recommend_amd device ops need tensors on a HIP device; "
+                               "there is no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------
+# host helpers (graph construction, sampler RNG): callable without a GPU
+# --------------------------------------------------------------------------
+def build_coo_host(users, items, ratings, n_users, n_items, add_self_loops):
+    """rk_build_coo_host on numpy arrays -> (src, dst, w) numpy int32/int32/float32."""
+    users = np.ascontiguousarray(users, dtype=np.int64)
+    items = np.ascontiguousarray(items, dtype=np.int64)
+    if ratings is not None:
+        ratings = np.ascontiguousarray(ratings, dtype=np.float32)
+    n = users.shape[0]
+    nnz = 2 * n + ((n_users + n_items) if add_self_loops else 0)
+    src = np.empty(nnz, np.int32)
+    dst = np.empty(nnz, np.int32)
+    w = np.empty(nnz, np.float32)
+    _ffi.call("rk_build_coo_host", ptr(users), ptr(items), ptr(ratings), c_int64(n),
+              c_int32(n_users), c_int32(n_items), c_int32(1 if add_self_loops else 0),
+              ptr(src), ptr(dst), ptr(w))
+    return src, dst, w
+
+
+def csr_from_coo_host(key, other, n_nodes):
+    """Stable sort of the COO by key -> (ptr, idx, eid) numpy int32."""
+    key = np.ascontiguousarray(key, dtype=np.int32)
+    other = np.ascontiguousarray(other, dtype=np.int32)
+    nnz = key.shape[0]
+    p = np.empty(n_nodes + 1, np.int32)
+    idx = np.empty(nnz, np.int32)
+    eid = np.empty(nnz, np.int32)
+    _ffi.call("rk_csr_from_coo_host", ptr(key), ptr(other), c_int64(nnz), c_int32(n_nodes),
+              ptr(p), ptr(idx), ptr(eid))
+    return p, idx, eid
+
+
+def spmm_plan_host(rowptr, long_thresh, chunk):
+    """Row binning of a CSR: (long_rows, long_chunk_ptr, chunk_begin, chunk_end) numpy int32."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    n_rows = rowptr.shape[0] - 1
+    nl, nc = c_int32(0), c_int32(0)
+    _ffi.call("rk_spmm_plan_host", ptr(rowptr), c_int32(n_rows), c_int32(long_thresh),
+              c_int32(chunk), ctypes.byref(nl), ctypes.byref(nc), None, None, None, None)
+    long_rows = np.empty(max(nl.value, 1), np.int32)
+    lcp = np.empty(nl.value + 1, np.int32)
+    cb = np.empty(max(nc.value, 1), np.int32)
+    ce = np.empty(max(nc.value, 1), np.int32)
+    _ffi.call("rk_spmm_plan_host", ptr(rowptr), c_int32(n_rows), c_int32(long_thresh),
+              c_int32(chunk), ctypes.byref(nl), ctypes.byref(nc), ptr(long_rows), ptr(lcp),
+              ptr(cb), ptr(ce))
+    return long_rows[:nl.value], lcp, cb[:nc.value], ce[:nc.value]
+
+
+# --------------------------------------------------------------------------
+# G2 / G3: normalisation and propagation
+# --------------------------------------------------------------------------
+class CsrMatrix:
+    """One sparse operand on one device: CSR arrays, edge values and the row
+    binning the SpMM kernels use.  `eid` maps CSR positions to COO edge ids."""
+
+    LONG_THRESH = 128
+    CHUNK = 256
+
+    def __init__(self, rowptr, idx, eid, device):
+        self.n_rows = int(rowptr.shape[0] - 1)
+        self.nnz = int(idx.shape[0])
+        self.device = torch.device(device)
+        lr, lcp, cb, ce = spmm_plan_host(rowptr, self.LONG_THRESH, self.CHUNK)
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.rowptr = to(rowptr)
+        self.idx = to(idx)
+        self.eid = to(eid)
+        self.n_long = int(lr.shape[0])
+        self.n_chunks = int(cb.shape[0])
+        self.long_rows = to(lr) if self.n_long else None
+        self.long_chunk_ptr = to(lcp) if self.n_long else None
+        self.chunk_begin = to(cb) if self.n_long else None
+        self.chunk_end = to(ce) if self.n_long else None
+        self.val = None          # fp32 [nnz] in CSR order
+        self._partial = {}       # D -> scratch for long-row chunks
+
+    def set_values_from_coo(self, w_coo):
+        """val[p] = w_coo[eid[p]]"""
+        _need_cuda(w_coo)
+        self.val = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
+        _ffi.call("rk_gather_f32", ptr(w_coo), ptr(self.eid), c_int64(self.nnz), ptr(self.val),
+                  stream_ptr(self.device))
+
+    def plan(self, D):
+        if not self.n_long:
+            return None, None
+        part = self._partial.get(D)
+        if part is None:
+            part = torch.empty(self.n_chunks * D, dtype=torch.float32, device=self.device)
+            self._partial[D] = part
+        p = _ffi.SpmmPlan(self.LONG_THRESH, self.n_long, self.long_rows.data_ptr(),
+                          self.long_chunk_ptr.data_ptr(), self.n_chunks,
+                          self.chunk_begin.data_ptr(), self.chunk_end.data_ptr(), part.data_ptr())
+        return p, part
+
+
+def spmm_raw(mat, h, h0=None, alpha=0.0, beta=1.0, out=None):
+    """out = A h  (h0 is None)  or  alpha*h0 + beta*(A h); no autograd."""
+    _need_cuda(h, h0)
+    if mat.val is None:
+        raise ValueError("sparse matrix has no edge values yet")
+    h = _f32c(h)
+    if h.dim() != 2 or h.shape[0] < 0:
+        raise ValueError("h must be [n_nodes, D]")
+    D = h.shape[1]
+    if out is None:
+        out = torch.empty((mat.n_rows, D), dtype=torch.float32, device=h.device)
+    if h0 is not None:
+        h0 = _f32c(h0)
+    plan, _keep = mat.plan(D)
+    _ffi.call("rk_spmm_csr_f32", ptr(mat.rowptr), ptr(mat.idx), ptr(mat.val), c_int32(mat.n_rows),
+              ptr(h), c_int32(D), ptr(out), ptr(h0), c_float(alpha), c_float(beta),
+              ctypes.byref(plan) if plan is not None else None, stream_ptr(h.device))
+    return out
+
+
+class _SpMM(torch.autograd.Function):
+    """out = alpha*h0 + beta*(A h); backward uses the transposed (CSC) operand."""
+
+    @staticmethod
+    def forward(ctx, h, h0, fwd_mat, bwd_mat, alpha, beta):
+        ctx.bwd_mat = bwd_mat
+        ctx.alpha, ctx.beta = alpha, beta
+        ctx.has_h0 = h0 is not None
+        return spmm_raw(fwd_mat, h, h0, alpha, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32c(g)
+        gh = gh0 = None
+        if ctx.needs_input_grad[0]:
+            gh = spmm_raw(ctx.bwd_mat, g)
+            if ctx.has_h0 and ctx.beta != 1.0:
+                gh = gh * ctx.beta
+        if ctx.has_h0 and ctx.needs_input_grad[1]:
+            gh0 = g * ctx.alpha
+        return gh, gh0, None, None, None, None
+
+
+def spmm(fwd_mat, bwd_mat, h, h0=None, alpha=0.0, beta=1.0):
+    return _SpMM.apply(h, h0, fwd_mat, bwd_mat, float(alpha), float(beta))
+
+
+def sym_normalize(mat, w_coo):
+    """graph_constructor.py:158-187 on the device; returns (sqrt_in_w, w_norm_coo)."""
+    _need_cuda(w_coo)
+    w_coo = _f32c(w_coo)
+    sq = torch.empty(mat.n_rows, dtype=torch.float32, device=w_coo.device)
+    out = torch.empty_like(w_coo)
+    _ffi.call("rk_sym_normalize_f32", ptr(mat.rowptr), ptr(mat.idx), ptr(mat.eid), ptr(w_coo),
+              c_int32(mat.n_rows), ptr(sq), ptr(out), stream_ptr(w_coo.device))
+    return sq, out
+
+
+def deg_normalize(mat):
+    """w_e = deg_in[src]^-0.5 * deg_in[dst]^-0.5 in COO order."""
+    out = torch.empty(mat.nnz, dtype=torch.float32, device=mat.device)
+    _ffi.require_device()
+    _ffi.call("rk_deg_normalize_f32", ptr(mat.rowptr), ptr(mat.idx), ptr(mat.eid),
+              c_int32(mat.n_rows), ptr(out), stream_ptr(mat.device))
+    return out
+
+
+# --------------------------------------------------------------------------
+# W1: modality projection
+# --------------------------------------------------------------------------
+class _Proj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_items, weight, bias, n_users):
+        _need_cuda(x_items, weight, bias)
+        x_items, weight = _f32c(x_items), _f32c(weight)
+        bias_c = _f32c(bias) if bias is not None else None
+        n_items, F = x_items.shape
+        D = weight.shape[0]
+        if weight.shape[1] != F:
+            raise ValueError(f"weight is {tuple(weight.shape)}, features are {F} wide")
+        y = torch.empty((n_users + n_items, D), dtype=torch.float32, device=x_items.device)
+        _ffi.call("rk_proj_fwd_f32", ptr(x_items), c_int32(n_items), c_int32(F), ptr(weight),
+                  ptr(bias_c), c_int32(D), c_int32(n_users), ptr(y), stream_ptr(y.device))
+        ctx.save_for_backward(x_items)
+        ctx.n_users, ctx.D, ctx.has_bias = n_users, D, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x_items,) = ctx.saved_tensors
+        g = _f32c(g)
+        n_items, F = x_items.shape
+        D, n_users = ctx.D, ctx.n_users
+        lib = _ffi.load()
+        ws_bytes = lib.rk_proj_bwd_ws_bytes(n_items, n_users, F, D)
+        ws = torch.empty(max(ws_bytes, 16) // 4 + 4, dtype=torch.float32, device=g.device)
+        dW = torch.empty((D, F), dtype=torch.float32, device=g.device)
+        db = torch.empty(D, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+        _ffi.call("rk_proj_bwd_f32", ptr(x_items), c_int32(n_items), c_int32(F), ptr(g),
+                  c_int32(D), c_int32(n_users), ptr(dW), ptr(db), ptr(ws),
+                  c_size_t(ws.numel() * 4), stream_ptr(g.device))
+        return None, dW, db, None
+
+
+def proj(x_items, weight, bias, n_users):
+    """[bias ; x_items @ weight.T + bias] as one (n_users + n_items) x D matrix."""
+    return _Proj.apply(x_items, weight, bias, int(n_users))
+
+
+# --------------------------------------------------------------------------
+# L1 / N: BPR gather-dot loss with optional in-kernel negative lookup
+# --------------------------------------------------------------------------
+class _Bpr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, I, users, pos, neg, mask, neg_rank, pos_ptr, pos_items, n_items):
+        _need_cuda(U, I, users, pos, neg, mask, neg_rank, pos_ptr, pos_items)
+        U, I = _f32c(U), _f32c(I)
+        users = users.to(torch.int64).contiguous()
+        pos = pos.to(torch.int64).contiguous()
+        B = users.shape[0]
+        if neg_rank is not None:
+            neg_rank = neg_rank.to(torch.int32).contiguous()
+            R = neg_rank.shape[1] if neg_rank.dim() == 2 else 1
+            neg = torch.empty((B, R), dtype=torch.int64, device=U.device)
+        else:
+            neg = neg.to(torch.int64).contiguous()
+            R = neg.shape[1] if neg.dim() == 2 else 1
+        if mask is not None:
+            mask = _f32c(mask)
+        D = U.shape[1]
+        lib = _ffi.load()
+        ws_bytes = lib.rk_bpr_ws_bytes(B, R)
+        ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=U.device)
+        x = torch.empty((max(B, 1), max(R, 1)), dtype=torch.float32, device=U.device)
+        out = torch.empty(2, dtype=torch.float32, device=U.device)
+        _ffi.call("rk_bpr_fwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
+                  c_int64(B), c_int32(R), ptr(mask), ptr(neg_rank), ptr(pos_ptr), ptr(pos_items),
+                  c_int32(int(n_items)), ptr(x), ptr(out), ptr(ws), c_size_t(ws.numel() * 4),
+                  stream_ptr(U.device))
+        ctx.save_for_backward(U, I, users, pos, neg, mask, x, out)
+        ctx.dims = (B, R, D)
+        ctx.mark_non_differentiable(neg)
+        return out[0], neg
+
+    @staticmethod
+    def backward(ctx, g, _gneg):
+        U, I, users, pos, neg, mask, x, out = ctx.saved_tensors
+        B, R, D = ctx.dims
+        g = _f32c(g).reshape(1)
+        dU = torch.zeros_like(U)
+        dI = torch.zeros_like(I)
+        _ffi.call("rk_bpr_bwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
+                  c_int64(B), c_int32(R), ptr(mask), ptr(x), ptr(out), ptr(g), ptr(dU), ptr(dI),
+                  stream_ptr(U.device))
+        return dU, dI, None, None, None, None, None, None, None, None
+
+
+def bpr_gather_dot(U, I, users, pos, neg, mask=None):
+    """mean(-logsigmoid(<U[u],I[i]> - <U[u],I[n]>)) over B x R (train/graph_trainer.py:255-270)."""
+    loss, _ = _Bpr.apply(U, I, users, pos, neg, mask, None, None, None, I.shape[0])
+    return loss
+
+
+def bpr_gather_dot_sampled(U, I, users, pos, neg_rank, pos_ptr, pos_items, mask=None):
+    """Same loss with negatives resolved in the kernel from per-sample ranks;
+    returns (loss, neg_items)."""
+    return _Bpr.apply(U, I, users, pos, None, mask, neg_rank, pos_ptr, pos_items, I.shape[0])
+
+
+# --------------------------------------------------------------------------
+# E1 / M: evaluation
+# --------------------------------------------------------------------------
+def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0):
+    """Top-K items per user of U @ I.T with masked pairs scored -1e10, without
+    materialising the score matrix.  Returns (scores [U,K] fp32, ids [U,K] int32)."""
+    _need_cuda(U, I, mask_ptr, mask_items)
+    U, I = _f32c(U.detach()), _f32c(I.detach())
+    n_users, D = U.shape
+    n_items = I.shape[0]
+    lib = _ffi.load()
+    ws_bytes = lib.rk_score_topk_ws_bytes(n_users, n_items, D, K)
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=U.device)
+    out_s = torch.empty((n_users, K), dtype=torch.float32, device=U.device)
+    out_i = torch.empty((n_users, K), dtype=torch.int32, device=U.device)
+    _ffi.call("rk_score_topk_f32", ptr(U), c_int32(n_users), ptr(I), c_int32(n_items), c_int32(D),
+              ptr(mask_ptr), ptr(mask_items), c_int32(K), c_int32(item_id_offset), ptr(out_s),
+              ptr(out_i), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(U.device))
+    return out_s, out_i
+
+
+def topk_merge(scores, ids, K):
+    """Merge candidate lists [U, P, Kin] into the best K per user by (score desc, id asc)."""
+    _need_cuda(scores, ids)
+    scores = _f32c(scores)
+    ids = ids.to(torch.int32).contiguous()
+    n_users, P, Kin = scores.shape
+    out_s = torch.empty((n_users, K), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((n_users, K), dtype=torch.int32, device=scores.device)
+    _ffi.call("rk_topk_merge_f32", ptr(scores), ptr(ids), c_int32(n_users), c_int32(P),
+              c_int32(Kin), c_int32(K), ptr(out_s), ptr(out_i), stream_ptr(scores.device))
+    return out_s, out_i
+
+
+def rank_metrics(topk_ids, tgt_ptr, tgt_items, k_list, mean_denominator=None, return_sums=False):
+    """evaluate_all_at_k for all k at once -> fp32 tensor [len(k_list), 6]
+    (precision, recall, hit_rate, ndcg, map, mrr), means over the rows."""
+    _need_cuda(topk_ids, tgt_ptr, tgt_items)
+    topk_ids = topk_ids.to(torch.int32).contiguous()
+    n_users, stride = topk_ids.shape
+    nk = len(k_list)
+    dev = topk_ids.device
+    kmax = max(k_list)
+    # discounts exactly as evalue/metric.py:130-131 builds them (fp32 torch ops)
+    disc = (1.0 / torch.log2(torch.arange(1, kmax + 1).float() + 1.0)).to(dev)
+    lib = _ffi.load()
+    ws_bytes = lib.rk_rank_metrics_ws_bytes(n_users, nk)
+    ws = torch.empty(ws_bytes // 8 + 2, dtype=torch.float64, device=dev)
+    out = torch.empty((nk, 6), dtype=torch.float32, device=dev)
+    sums = torch.empty((nk, 6), dtype=torch.float64, device=dev) if return_sums else None
+    kl = (c_int32 * nk)(*[int(k) for k in k_list])
+    denom = int(mean_denominator) if mean_denominator is not None else n_users
+    _ffi.call("rk_rank_metrics_f32", ptr(topk_ids), c_int32(n_users), c_int32(stride),
+              ptr(tgt_ptr), ptr(tgt_items), kl, c_int32(nk), ptr(disc), ptr(out), ptr(sums),
+              c_int64(denom), ptr(ws), c_size_t(ws.numel() * 8), stream_ptr(dev))
+    return (out, sums) if return_sums else out

@@ -1,0 +1,120 @@
+"""Negative sampling and training-batch production.
+
+Restates the behaviour of GraphDataLoader (data/graph_data_loader.py:321-447 of
+the reference) without pandas/DataLoader workers: the shuffle order comes from
+the same torch RNG calls the DataLoader makes, the negative draws from the same
+MT19937 stream CPython's `random` module uses (host part of librecommend_amd),
+and the negative item ids are either resolved on the host (reference batch
+layout, `neg_items`) or left as ranks that the BPR kernel resolves (`neg_rank`).
+"""
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import c_int32, c_int64, ptr
+
+
+def build_user_csr(users, items, n_users):
+    """Per-user sorted unique item lists as CSR (ptr int32 [U+1], items int32)."""
+    users = np.asarray(users, dtype=np.int64)
+    items = np.asarray(items, dtype=np.int64)
+    if users.shape[0] == 0:
+        return np.zeros(n_users + 1, np.int32), np.zeros(0, np.int32)
+    key = np.unique(users * (int(items.max()) + 1) + items)
+    m = int(items.max()) + 1
+    u = key // m
+    it = (key % m).astype(np.int32)
+    ptr_ = np.zeros(n_users + 1, np.int64)
+    np.add.at(ptr_, u + 1, 1)
+    return np.cumsum(ptr_).astype(np.int32), it
+
+
+class NegativeSampler:
+    """random.sample over the ascending list of items the user never touched
+    (graph_data_loader.py:373-397), with CPython's generator state kept here."""
+
+    def __init__(self, pos_ptr, pos_items, n_items, seed=42, neg_ratio=1):
+        if neg_ratio <= 0:
+            raise ValueError("Negative ratio must be greater than zero")
+        self.pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int32)
+        self.pos_items = np.ascontiguousarray(pos_items, dtype=np.int32)
+        self.n_items = int(n_items)
+        self.neg_ratio = int(neg_ratio)
+        self.state = np.zeros(625, np.uint32)
+        self.seed(seed)
+        self._dev = {}
+
+    def seed(self, seed):
+        """random.seed(seed) for a non-negative int below 2**64."""
+        _ffi.call("rk_mt_seed_host", ptr(self.state), _ffi.c_uint64(int(seed)))
+
+    def sample(self, user_ids, want_ids=True):
+        """-> (ranks int32 [B,R], neg_items int64 [B,R] or None) as numpy arrays;
+        consumes the MT19937 stream exactly like one _generate_negative_samples call."""
+        users = np.ascontiguousarray(
+            user_ids.cpu().numpy() if isinstance(user_ids, torch.Tensor) else user_ids,
+            dtype=np.int64)
+        B = users.shape[0]
+        ranks = np.empty((B, self.neg_ratio), np.int32)
+        neg = np.empty((B, self.neg_ratio), np.int64) if want_ids else None
+        _ffi.call("rk_neg_sample_host", ptr(self.state), ptr(users), c_int64(B),
+                  c_int32(self.neg_ratio), ptr(self.pos_ptr), ptr(self.pos_items),
+                  c_int32(self.n_items), ptr(ranks), ptr(neg))
+        return ranks, neg
+
+    def device_csr(self, device):
+        """User->positives CSR in HBM for the in-kernel negative lookup."""
+        device = torch.device(device)
+        if device not in self._dev:
+            self._dev[device] = (torch.from_numpy(self.pos_ptr).to(device),
+                                 torch.from_numpy(self.pos_items).to(device))
+        return self._dev[device]
+
+
+class TrainBatchLoader:
+    """Iterates shuffled training batches as dicts with the reference's keys
+    (`user_ids`, `item_ids`, `ratings`, `neg_items`) plus `neg_rank`.
+
+    Shuffle order: the reference wraps a torch DataLoader(shuffle=True); creating
+    its iterator draws one int64 (the loader's base seed) and the RandomSampler
+    draws a second one to seed the generator behind torch.randperm.  The same two
+    draws are made here so a run seeded like the reference sees the same batches
+    (num_workers=0 behaviour)."""
+
+    def __init__(self, users, items, ratings, batch_size, sampler=None, shuffle=True,
+                 device=None, resolve_on_host=True):
+        self.users = torch.as_tensor(np.asarray(users), dtype=torch.int64)
+        self.items = torch.as_tensor(np.asarray(items), dtype=torch.int64)
+        self.ratings = None if ratings is None else torch.as_tensor(np.asarray(ratings), dtype=torch.float32)
+        self.batch_size = int(batch_size)
+        self.sampler = sampler
+        self.shuffle = shuffle
+        self.device = device
+        self.resolve_on_host = resolve_on_host
+
+    def __len__(self):
+        return (self.users.shape[0] + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.users.shape[0]
+        if self.shuffle:
+            torch.empty((), dtype=torch.int64).random_()          # DataLoader base seed
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(seed)
+            order = torch.randperm(n, generator=g)
+        else:
+            order = torch.arange(n)
+        for b in range(0, n, self.batch_size):
+            idx = order[b:b + self.batch_size]
+            batch = {"user_ids": self.users[idx], "item_ids": self.items[idx]}
+            if self.ratings is not None:
+                batch["ratings"] = self.ratings[idx]
+            if self.sampler is not None:
+                ranks, neg = self.sampler.sample(batch["user_ids"], want_ids=self.resolve_on_host)
+                batch["neg_rank"] = torch.from_numpy(ranks)
+                if neg is not None:
+                    batch["neg_items"] = torch.from_numpy(neg)
+            if self.device is not None:
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            yield batch
