@@ -39,7 +39,7 @@ inline int choose_nsplit(int n_users, int n_items) {
   const int utiles = (int)rk::ceil_div(n_users, UPB);
   const int tiles = (int)rk::ceil_div(n_items, TI);
   int ns = 1;
-  while (utiles * ns < 2048 && ns < 64 && tiles / (ns * 2) >= 4) ns *= 2;
+  while (utiles * ns < 2048 && ns < 16 && tiles / (ns * 2) >= 4) ns *= 2;  // 2*ns*32 <= MERGE_MAX
   return ns;
 }
 

@@ -226,6 +226,82 @@ inline int64_t kth_missing(const int32_t *pos, int32_t len, int64_t rank) {
 
 }  // namespace
 
+}  // extern "C"
+
+namespace {
+// CPython set emulation.  `list(all_items - pos)` iterates the result set in
+// hash-table slot order.  When len(pos) < len(all_items) >> 2 CPython copies
+// all_items (table larger than twice the item count, so a dense id sits in slot
+// id) and removes pos: ascending ids.  Otherwise it inserts the surviving ids one
+// by one into a fresh table that grows as it fills; ids at or above the table
+// size wrap around and the order is no longer ascending.  CandidateOrder
+// rebuilds that table (Objects/setobject.c: set_add_entry, set_table_resize,
+// set_insert_clean; LINEAR_PROBES 9, PERTURB_SHIFT 5, hash(int) = int).
+struct CandidateOrder {
+  std::vector<int32_t> key;
+  std::vector<uint8_t> used;
+  size_t mask = 7, fill = 0;
+
+  void insert_clean(std::vector<int32_t> &k, std::vector<uint8_t> &u, size_t m, int32_t id) {
+    size_t perturb = (size_t)id, i = (size_t)id & m;
+    while (true) {
+      if (!u[i]) { u[i] = 1; k[i] = id; return; }
+      if (i + 9 <= m) {
+        for (size_t j = 1; j <= 9; ++j)
+          if (!u[i + j]) { u[i + j] = 1; k[i + j] = id; return; }
+      }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & m;
+    }
+  }
+  void resize(size_t minused) {
+    size_t newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    std::vector<int32_t> nk(newsize);
+    std::vector<uint8_t> nu(newsize, 0);
+    for (size_t e = 0; e <= mask; ++e)
+      if (used[e]) insert_clean(nk, nu, newsize - 1, key[e]);
+    key.swap(nk);
+    used.swap(nu);
+    mask = newsize - 1;
+  }
+  void add(int32_t id) {
+    size_t perturb = (size_t)id, i = (size_t)id & mask;
+    while (true) {
+      const size_t probes = (i + 9 <= mask) ? 9 : 0;
+      for (size_t j = 0; j <= probes; ++j)
+        if (!used[i + j]) {
+          used[i + j] = 1;
+          key[i + j] = id;
+          ++fill;
+          if (fill * 5 >= mask * 3) resize(fill > 50000 ? fill * 2 : fill * 4);
+          return;
+        }
+      perturb >>= 5;
+      i = (i * 5 + 1 + perturb) & mask;
+    }
+  }
+  // candidate ids of one user in the order list(all_items - pos) yields them
+  void build(const int32_t *pos, int32_t len, int32_t n_items, std::vector<int32_t> &out) {
+    key.assign(8, 0);
+    used.assign(8, 0);
+    mask = 7;
+    fill = 0;
+    int32_t p = 0;
+    for (int32_t id = 0; id < n_items; ++id) {
+      if (p < len && pos[p] == id) { ++p; continue; }
+      add(id);
+    }
+    out.clear();
+    for (size_t e = 0; e <= mask; ++e)
+      if (used[e]) out.push_back(key[e]);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
 int rk_mt_seed_host(uint32_t *state, uint64_t seed) {
   RK_CHECK_ARG(state, "null state");
   // random.seed(int): key = little-endian 32-bit words of abs(seed), at least one word
@@ -250,7 +326,8 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
     while (p < 3 * (int64_t)R) p *= 4;
     setsize += p;
   }
-  std::vector<int32_t> pool, sel;
+  std::vector<int32_t> pool, sel, order;
+  CandidateOrder emu;
   for (int64_t s = 0; s < B; ++s) {
     const int64_t u = users[s];
     const int32_t *pos = pos_items + pos_ptr[u];
@@ -270,13 +347,25 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
       }
       continue;
     }
+    // set_difference takes the copy-and-remove path iff (len(all_items) >> 2) > len(pos)
+    const bool ascending = (n_items >> 2) > len;
+    if (!ascending) emu.build(pos, len, n_items, order);
+    // j-th candidate of the reference's list -> item id and its ascending rank
+    auto emit = [&](int32_t r, int64_t j) {
+      int64_t item, rank;
+      if (ascending) {
+        rank = j;
+        item = kth_missing(pos, len, j);
+      } else {
+        item = order[(size_t)j];
+        rank = item - (std::lower_bound(pos, pos + len, (int32_t)item) - pos);
+      }
+      if (rk) rk[r] = (int32_t)rank;
+      if (ng) ng[r] = item;
+    };
     if (n < R) {
       // random.choices(cands, k=R): floor(random() * n)
-      for (int32_t r = 0; r < R; ++r) {
-        const int64_t j = (int64_t)(mt_random(state) * (double)n);
-        if (rk) rk[r] = (int32_t)j;
-        if (ng) ng[r] = kth_missing(pos, len, j);
-      }
+      for (int32_t r = 0; r < R; ++r) emit(r, (int64_t)(mt_random(state) * (double)n));
     } else if (n <= setsize) {
       pool.resize((size_t)n);
       for (int64_t q = 0; q < n; ++q) pool[(size_t)q] = (int32_t)q;
@@ -284,8 +373,7 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
         const uint32_t j = mt_randbelow(state, (uint32_t)(n - r));
         const int32_t pick = pool[j];
         pool[j] = pool[(size_t)(n - r - 1)];
-        if (rk) rk[r] = pick;
-        if (ng) ng[r] = kth_missing(pos, len, pick);
+        emit(r, pick);
       }
     } else {
       sel.clear();
@@ -294,8 +382,7 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
         while (std::find(sel.begin(), sel.end(), (int32_t)j) != sel.end())
           j = mt_randbelow(state, (uint32_t)n);
         sel.push_back((int32_t)j);
-        if (rk) rk[r] = (int32_t)j;
-        if (ng) ng[r] = kth_missing(pos, len, j);
+        emit(r, j);
       }
     }
   }

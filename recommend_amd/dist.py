@@ -1,0 +1,98 @@
+"""Multi-GPU partitioning of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box).
+
+Full-ranking evaluation shards the ITEM table: rank r scores every user against
+items [lo_r, hi_r) only, keeps its local top-K (ids are global), the per-rank
+lists are exchanged with one all-gather of U*K*(4+4) bytes per rank, every rank
+merges the lists of its own slice of users, reduces the metric sums of that
+slice, and one all-reduce of 6*len(k_list) doubles finishes the means.  Contiguous
+item ranges keep "lower id wins" valid across shards.
+
+The reference is single-process (no collective anywhere in its tree); this file
+has no counterpart there.  `compute` is the module that provides score_topk /
+topk_merge / rank_metrics: recommend_amd.ops (HIP) in production.
+"""
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .evaluator import METRIC_ORDER, pairs_to_csr, restrict_csr, target_to_csr, _pad64
+
+
+def item_range(n_items, rank, world):
+    return (n_items * rank) // world, (n_items * (rank + 1)) // world
+
+
+def user_range(n_users, rank, world):
+    return (n_users * rank) // world, (n_users * (rank + 1)) // world
+
+
+class ShardedRankingEvaluator:
+    def __init__(self, target, mask, k_list: Sequence[int], metrics: Sequence[str], n_users: int,
+                 n_items: int, rank: Optional[int] = None, world: Optional[int] = None,
+                 group=None, compute=None):
+        if compute is None:
+            from . import ops as compute  # the HIP path; raises without a GPU
+        self.compute = compute
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.k_list = [int(k) for k in k_list]
+        self.metrics = list(metrics)
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.lo, self.hi = item_range(self.n_items, self.rank, self.world)
+        self.u_lo, self.u_hi = user_range(self.n_users, self.rank, self.world)
+        row_id, col_id = mask
+        mp, mc = pairs_to_csr(row_id, col_id, self.n_users)
+        self.mask_ptr, self.mask_items = restrict_csr(mp, mc, self.lo, self.hi)
+        tp, tc = target_to_csr(target, self.n_users)
+        # targets of this rank's user slice only
+        self.tgt_ptr = (tp[self.u_lo:self.u_hi + 1] - tp[self.u_lo]).astype(np.int32)
+        self.tgt_items = tc[tp[self.u_lo]:tp[self.u_hi]].astype(np.int32)
+        self._dev = {}
+
+    def _state(self, device):
+        device = torch.device(device)
+        st = self._dev.get(device)
+        if st is None:
+            to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            st = {k: to(getattr(self, k)) for k in ("mask_ptr", "mask_items", "tgt_ptr", "tgt_items")}
+            self._dev[device] = st
+        return st
+
+    def local_topk(self, user_embeddings, item_embeddings_full, k):
+        st = self._state(user_embeddings.device)
+        shard = item_embeddings_full[self.lo:self.hi]
+        return self.compute.score_topk(_pad64(user_embeddings), _pad64(shard), k, st["mask_ptr"],
+                                       st["mask_items"], item_id_offset=self.lo)
+
+    def evaluate(self, user_embeddings, item_embeddings_full) -> Dict[str, torch.Tensor]:
+        kmax = max(self.k_list)
+        if kmax > self.hi - self.lo:
+            raise ValueError("k must be in the range [1, num_items of the smallest shard]")
+        st = self._state(user_embeddings.device)
+        s, ids = self.local_topk(user_embeddings, item_embeddings_full, kmax)
+        # one exchange step: every rank's [U, K] lists
+        gs = [torch.empty_like(s) for _ in range(self.world)]
+        gi = [torch.empty_like(ids) for _ in range(self.world)]
+        dist.all_gather(gs, s.contiguous(), group=self.group)
+        dist.all_gather(gi, ids.contiguous(), group=self.group)
+        sl = slice(self.u_lo, self.u_hi)
+        cand_s = torch.stack([g[sl] for g in gs], dim=1).contiguous()     # [u, world, K]
+        cand_i = torch.stack([g[sl] for g in gi], dim=1).contiguous()
+        sums = torch.zeros((len(self.k_list), 6), dtype=torch.float64, device=s.device)
+        self.last_ids = None
+        if self.u_hi > self.u_lo:
+            _ms, mi = self.compute.topk_merge(cand_s, cand_i, kmax)
+            self.last_ids = mi
+            _out, sums = self.compute.rank_metrics(mi, st["tgt_ptr"], st["tgt_items"], self.k_list,
+                                                   mean_denominator=self.n_users, return_sums=True)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        table = (sums / float(self.n_users)).to(torch.float32).cpu()
+        out = {}
+        for ki, k in enumerate(self.k_list):
+            for name in self.metrics:
+                out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
+        return out

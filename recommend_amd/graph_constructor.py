@@ -108,7 +108,8 @@ class GraphConstructor:
         self.num_interactions = len(interactions[0]) if _is_array_triplet(interactions) else len(interactions)
 
         if _is_array_triplet(interactions):
-            users, items, ratings = (np.asarray(a) for a in interactions)
+            users, items = np.asarray(interactions[0]), np.asarray(interactions[1])
+            ratings = None if interactions[2] is None else np.asarray(interactions[2])
         elif len(interactions) == 0:
             users = np.zeros(0, np.int64)
             items = np.zeros(0, np.int64)
@@ -262,6 +263,5 @@ class GraphConstructor:
 
 
 def _is_array_triplet(x):
-    return (isinstance(x, tuple) and len(x) == 3
-            and all(hasattr(a, "__len__") and not isinstance(a, tuple) for a in x)
-            and hasattr(x[0], "shape"))
+    return (isinstance(x, tuple) and len(x) == 3 and hasattr(x[0], "shape")
+            and hasattr(x[1], "shape") and (x[2] is None or hasattr(x[2], "shape")))

@@ -93,7 +93,8 @@ class CsrMatrix:
         self.nnz = int(idx.shape[0])
         self.device = torch.device(device)
         lr, lcp, cb, ce = spmm_plan_host(rowptr, self.LONG_THRESH, self.CHUNK)
-        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        # empty arrays are padded to one element so that no NULL pointer reaches the library
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros(1, a.dtype))).to(self.device)
         self.rowptr = to(rowptr)
         self.idx = to(idx)
         self.eid = to(eid)
@@ -109,7 +110,7 @@ class CsrMatrix:
     def set_values_from_coo(self, w_coo):
         """val[p] = w_coo[eid[p]]"""
         _need_cuda(w_coo)
-        self.val = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
+        self.val = torch.zeros(max(self.nnz, 1), dtype=torch.float32, device=self.device)
         _ffi.call("rk_gather_f32", ptr(w_coo), ptr(self.eid), c_int64(self.nnz), ptr(self.val),
                   stream_ptr(self.device))
 
@@ -303,6 +304,8 @@ def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0):
     materialising the score matrix.  Returns (scores [U,K] fp32, ids [U,K] int32)."""
     _need_cuda(U, I, mask_ptr, mask_items)
     U, I = _f32c(U.detach()), _f32c(I.detach())
+    if mask_items is None or mask_items.numel() == 0:
+        mask_ptr = mask_items = None
     n_users, D = U.shape
     n_items = I.shape[0]
     lib = _ffi.load()
@@ -334,6 +337,8 @@ def rank_metrics(topk_ids, tgt_ptr, tgt_items, k_list, mean_denominator=None, re
     (precision, recall, hit_rate, ndcg, map, mrr), means over the rows."""
     _need_cuda(topk_ids, tgt_ptr, tgt_items)
     topk_ids = topk_ids.to(torch.int32).contiguous()
+    if tgt_items.numel() == 0:
+        tgt_items = torch.zeros(1, dtype=torch.int32, device=topk_ids.device)
     n_users, stride = topk_ids.shape
     nk = len(k_list)
     dev = topk_ids.device

@@ -57,7 +57,7 @@ def make_interactions(n_users, n_items, n_inter, seed=42, min_per_user=5):
     cdf[-1] = 1.0
     items = np.searchsorted(cdf, rng.random(E), side="right").astype(np.int64)
     # re-draw duplicate (user, item) pairs until all pairs are unique
-    for _ in range(200):
+    for attempt in range(200):
         key = users * n_items + items
         order = np.argsort(key, kind="stable")
         dup = np.zeros(E, bool)
@@ -65,6 +65,14 @@ def make_interactions(n_users, n_items, n_inter, seed=42, min_per_user=5):
         n_dup = int(dup.sum())
         if n_dup == 0:
             break
+        if attempt >= 20:
+            # near-saturated users: give each duplicate an item the user does not have yet
+            for u in np.unique(users[dup]):
+                mine = np.flatnonzero(users == u)
+                d_u = mine[dup[mine]]
+                free = np.setdiff1d(np.arange(n_items), items[mine[~dup[mine]]])
+                items[d_u] = rng.choice(free, d_u.shape[0], replace=False)
+            continue
         # heavy users exhaust the popular items: fall back to uniform draws for them
         items[dup] = rng.integers(0, n_items, n_dup)
     else:

@@ -1,0 +1,199 @@
+"""GPU parity: fused score + mask + top-K, list merge and ranking metrics against
+the golden vectors of the reference's Verifier and the exact oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle
+from recommend_amd import ops, synth
+from recommend_amd.evaluator import Tester, Verifier, RankingEvaluator, pairs_to_csr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
+
+
+class Cfg:
+    class evaluation:
+        metrics = METRICS
+        k_values = [5, 10, 20]
+    class system:
+        device = DEV
+    class data:
+        num_users = -1
+
+
+class Stub:
+    def __init__(self, u, i):
+        self.u, self.i, self.evaled = u, i, False
+
+    def eval(self):
+        self.evaled = True
+
+    def __call__(self, batch):
+        assert batch == {}
+        return {"user_embeddings": self.u, "item_embeddings": self.i}
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+@pytest.mark.parametrize("name", ["v96x300", "v200x1000"])
+def test_verifier_and_tester_vs_reference(golden, name):
+    z = golden("verifier_cases.npz")
+    ue, ie = dev(z[f"{name}/user_emb"]), dev(z[f"{name}/item_emb"])
+    tr, va = z[f"{name}/train_pairs"], z[f"{name}/val_pairs"]
+    target = torch.zeros(ue.shape[0], ie.shape[0])
+    target[va[:, 0], va[:, 1]] = 1
+    mask = (tr[:, 0].tolist(), tr[:, 1].tolist())
+    model = Stub(ue, ie)
+    res = Verifier(Cfg, None, target, mask).verify(model)
+    assert model.evaled
+    assert list(res.keys()) == [str(k) for k in z[f"{name}/keys"]]
+    for v in res.values():
+        assert isinstance(v, torch.Tensor) and v.dim() == 0
+    np.testing.assert_allclose([float(v) for v in res.values()], z[f"{name}/values"], rtol=1e-5, atol=1e-7)
+    res_t = Tester(Cfg, None, target, mask).test(Stub(ue, ie))
+    assert {k: float(v) for k, v in res_t.items()} == {k: float(v) for k, v in res.items()}
+    # ranked ids equal the reference's torch.topk ids (fixture has no near-ties) ...
+    ev = RankingEvaluator(target, mask, [5, 10, 20], METRICS)
+    scores, ids = ev.topk(ue, ie, 20)
+    np.testing.assert_array_equal(ids.cpu().numpy(), z[f"{name}/topk20"])
+    # ... and ids AND scores equal the exact oracle bit for bit
+    ptr, cols = pairs_to_csr(tr[:, 0], tr[:, 1], ue.shape[0])
+    o_s, o_i = eval_oracle.score_topk(z[f"{name}/user_emb"], z[f"{name}/item_emb"], 20, ptr, cols)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(scores.cpu().numpy(), o_s)
+    # sparse target input gives the same result
+    res_sp = RankingEvaluator((va[:, 0], va[:, 1]), mask, [5, 10, 20], METRICS, n_users=ue.shape[0]).evaluate(ue, ie)
+    assert {k: float(v) for k, v in res_sp.items()} == {k: float(v) for k, v in res.items()}
+
+
+@pytest.mark.parametrize("U,I,D,K", [(1, 1, 64, 1), (5, 7, 64, 7), (129, 33, 64, 20), (300, 1000, 128, 32),
+                                      (257, 4099, 64, 20), (1000, 257, 64, 5), (64, 20000, 64, 10)])
+def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K):
+    """Quantised embeddings give many exactly equal scores: ids must come out in
+    (score desc, id asc) order, identical to the oracle, for awkward shapes."""
+    rng = np.random.default_rng(U * 7 + I)
+    ue = (np.round(rng.standard_normal((U, D)) * 2) / 2).astype(np.float32)
+    ie = (np.round(rng.standard_normal((I, D)) * 2) / 2).astype(np.float32)
+    n_mask = min(U * I // 3, U * 40)
+    rows, cols = rng.integers(0, U, n_mask), rng.integers(0, I, n_mask)
+    if U > 2:   # one user with everything masked, one with nothing
+        rows = np.concatenate([rows[rows > 1], np.zeros(I, np.int64)])
+        cols = np.concatenate([cols[:rows.shape[0] - I], np.arange(I)])
+    ptr, mcols = pairs_to_csr(rows, cols, U)
+    s, ids = ops.score_topk(dev(ue), dev(ie), K, dev(ptr), dev(mcols))
+    o_s, o_i = eval_oracle.score_topk(ue, ie, K, ptr, mcols)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+    # no mask at all
+    s2, ids2 = ops.score_topk(dev(ue), dev(ie), K)
+    o_s2, o_i2 = eval_oracle.score_topk(ue, ie, K)
+    np.testing.assert_array_equal(ids2.cpu().numpy(), o_i2)
+    np.testing.assert_array_equal(s2.cpu().numpy(), o_s2)
+
+
+def test_item_offset_and_merge_equal_unsharded():
+    """Two item shards ranked separately and merged give the unsharded ranking."""
+    rng = np.random.default_rng(4)
+    U, I, D, K = 500, 3001, 64, 20
+    ue = (np.round(rng.standard_normal((U, D)) * 4) / 4).astype(np.float32)
+    ie = (np.round(rng.standard_normal((I, D)) * 4) / 4).astype(np.float32)
+    rows, cols = rng.integers(0, U, 5000), rng.integers(0, I, 5000)
+    ptr, mcols = pairs_to_csr(rows, cols, U)
+    full_s, full_i = ops.score_topk(dev(ue), dev(ie), K, dev(ptr), dev(mcols))
+    from recommend_amd.evaluator import restrict_csr
+    parts_s, parts_i = [], []
+    for lo, hi in ((0, 1400), (1400, I)):
+        p2, c2 = restrict_csr(ptr, mcols, lo, hi)
+        s, i = ops.score_topk(dev(ue), dev(ie[lo:hi]), K, dev(p2), dev(c2), item_id_offset=lo)
+        parts_s.append(s), parts_i.append(i)
+    ms, mi = ops.topk_merge(torch.stack(parts_s, 1), torch.stack(parts_i, 1), K)
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    # padding entries (id < 0) never win
+    pad_s = torch.full((U, 1, K), float("inf"), device=DEV)
+    pad_i = torch.full((U, 1, K), -1, dtype=torch.int32, device=DEV)
+    ms2, mi2 = ops.topk_merge(torch.cat([torch.stack(parts_s, 1), pad_s], 1),
+                              torch.cat([torch.stack(parts_i, 1), pad_i], 1), K)
+    assert torch.equal(mi2, full_i)
+
+
+def test_rank_metrics_vs_reference_cases(golden):
+    z = golden("metric_cases.npz")
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        t = z[f"{name}/targets"]
+        ks = [int(k) for k in z[f"{name}/ks"] if k <= 32]
+        kmax = max(ks)
+        ids = z[f"{name}/topk@{kmax}"].astype(np.int32)
+        nz = np.argwhere(t != 0)
+        ptr, cols = pairs_to_csr(nz[:, 0], nz[:, 1], t.shape[0])
+        out = ops.rank_metrics(dev(ids), dev(ptr), dev(cols), ks).cpu().numpy()
+        for j, k in enumerate(ks):
+            np.testing.assert_allclose(out[j], z[f"{name}/all@{k}"], rtol=1e-5, atol=1e-7)
+
+
+def test_validation_errors_match_reference(golden):
+    ue, ie = torch.randn(6, 64, device=DEV), torch.randn(9, 64, device=DEV)
+    target = torch.zeros(6, 9)
+
+    class C(Cfg):
+        class evaluation:
+            metrics = METRICS
+            k_values = [5, 10]
+    with pytest.raises(ValueError, match=r"k must be in the range \[1, num_items\]"):
+        Verifier(C, None, target, ([], [])).verify(Stub(ue, ie))
+    with pytest.raises(ValueError, match="same shape"):
+        Verifier(Cfg, None, torch.zeros(6, 8), ([], [])).verify(Stub(ue, ie))
+
+
+def test_embedding_width_not_multiple_of_64():
+    rng = np.random.default_rng(8)
+    U, I, D = 200, 500, 48
+    ue, ie = rng.standard_normal((U, D)).astype(np.float32), rng.standard_normal((I, D)).astype(np.float32)
+    ev = RankingEvaluator((np.array([0]), np.array([1])), ([0], [2]), [5], METRICS, n_users=U)
+    _s, ids = ev.topk(dev(ue), dev(ie), 5)
+    pad = lambda x: np.pad(x, ((0, 0), (0, 16)))
+    ptr, cols = pairs_to_csr([0], [2], U)
+    _os, o_i = eval_oracle.score_topk(pad(ue), pad(ie), 5, ptr, cols)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
+
+
+def test_baby_shape_end_to_end_vs_oracle():
+    """Full Baby shape (19,445 x 7,050): ids exact vs the oracle on a user sample,
+    metrics within 1e-5 of the oracle's on all users, idempotent across runs."""
+    d = synth.make_named("baby")
+    rng = np.random.default_rng(0)
+    D = 64
+    ue = (rng.standard_normal((d.n_users, D)) * 0.1).astype(np.float32)
+    ie = (rng.standard_normal((d.n_items, D)) * 0.1).astype(np.float32)
+    tu, ti, _ = d.split(0)
+    vu, vi, _ = d.split(1)
+    ev = RankingEvaluator((vu, vi), (tu, ti), [5, 10, 20], METRICS, n_users=d.n_users)
+    res = ev.evaluate(dev(ue), dev(ie))
+    s, ids = ev.topk(dev(ue), dev(ie), 20)
+    s2, ids2 = ev.topk(dev(ue), dev(ie), 20)
+    assert torch.equal(ids, ids2) and torch.equal(s, s2)
+    ids = ids.cpu().numpy()
+    sample = np.sort(rng.choice(d.n_users, 1500, replace=False))
+    for a in range(0, len(sample), 500):     # oracle in chunks of users
+        us = sample[a:a + 500]
+        ptr, cols = pairs_to_csr(tu, ti, d.n_users)
+        sub_ptr = np.concatenate([[0], np.cumsum(ptr[us + 1] - ptr[us])]).astype(np.int32)
+        sub_cols = np.concatenate([cols[ptr[u]:ptr[u + 1]] for u in us]).astype(np.int32)
+        _os, o_i = eval_oracle.score_topk(ue[us], ie, 20, sub_ptr, sub_cols)
+        np.testing.assert_array_equal(ids[us], o_i)
+    # masked items never appear; ids are unique per user
+    ptr, cols = pairs_to_csr(tu, ti, d.n_users)
+    width = d.n_items
+    train_keys = np.repeat(np.arange(d.n_users), np.diff(ptr)) * width + cols
+    got_keys = (np.arange(d.n_users)[:, None] * width + ids).ravel()
+    assert not np.isin(got_keys, train_keys).any()
+    assert all(len(set(r)) == 20 for r in ids[:2000])
+    tp, tc = pairs_to_csr(vu, vi, d.n_users)
+    want = eval_oracle.metrics_from_topk_sparse(ids, tp, tc, [5, 10, 20])
+    for k in (5, 10, 20):
+        for m in METRICS:
+            assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)

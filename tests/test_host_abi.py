@@ -1,0 +1,152 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every
+symbol the header declares, and its host entry points (edge list, CSR sort, row
+binning, MT19937 negative sampler, batch loader) are bit-exact against the
+oracle and against the batches captured from the reference's own loader.
+No device entry point is called here."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph_oracle, sampler_oracle
+from recommend_amd import _ffi, ops
+from recommend_amd.sampler import NegativeSampler, TrainBatchLoader, build_user_csr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "recommend_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    # and every symbol the Python side binds is declared in the header
+    assert sorted(_ffi.SIGNATURES) == names
+    assert lib.rk_abi_version() == 1
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert _ffi.device_count() == 0
+    with pytest.raises(_ffi.RkError):
+        _ffi.require_device()
+    with pytest.raises(_ffi.RkError):
+        ops.spmm_raw(None, torch.zeros(4, 64))
+    with pytest.raises(_ffi.RkError):
+        ops.score_topk(torch.zeros(4, 64), torch.zeros(8, 64), 2)
+
+
+def test_argument_errors_are_reported():
+    lib = _ffi.load()
+    rc = lib.rk_spmm_csr_f32(None, None, None, 5, None, 64, None, None, 0.0, 1.0, None, None)
+    assert rc == _ffi.RK_ERR_ARG and "null" in _ffi.last_error()
+    st = np.zeros(625, np.uint32)
+    with pytest.raises(_ffi.RkError, match="Negative ratio must be greater than zero"):
+        _ffi.call("rk_neg_sample_host", _ffi.ptr(st), _ffi.ptr(np.zeros(1, np.int64)), 1, 0,
+                  _ffi.ptr(np.zeros(2, np.int32)), _ffi.ptr(np.zeros(1, np.int32)), 5, None, None)
+    with pytest.raises(_ffi.RkError, match="out of range"):
+        ops.build_coo_host([0, 7], [0, 0], [1.0, 1.0], 3, 2, True)
+
+
+@pytest.mark.parametrize("self_loops", [True, False])
+def test_coo_and_csr_bit_exact_vs_oracle(self_loops):
+    rng = np.random.default_rng(3)
+    U, I, E = 50, 37, 400
+    users, items = rng.integers(0, U, E), rng.integers(0, I, E)      # duplicates kept (multi-edges)
+    ratings = rng.integers(1, 6, E).astype(np.float32)
+    inter = [(int(u), int(i), float(r)) for u, i, r in zip(users, items, ratings)]
+    o_src, o_dst, o_w = graph_oracle.build_coo(inter, U, I, self_loops)
+    src, dst, w = ops.build_coo_host(users, items, ratings, U, I, self_loops)
+    np.testing.assert_array_equal(src, o_src), np.testing.assert_array_equal(dst, o_dst)
+    np.testing.assert_array_equal(w, o_w)
+    for key, other in ((dst, src), (src, dst)):
+        p, idx, eid = ops.csr_from_coo_host(key, other, U + I)
+        op, oidx, oeid = graph_oracle.csr_from_coo(key, other, U + I)
+        np.testing.assert_array_equal(p, op), np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_array_equal(eid, oeid)
+
+
+def test_empty_graph_and_no_ratings():
+    src, dst, w = ops.build_coo_host([], [], None, 3, 2, True)
+    np.testing.assert_array_equal(src, np.arange(5)), np.testing.assert_array_equal(w, np.zeros(5, np.float32))
+    p, idx, eid = ops.csr_from_coo_host(dst, src, 5)
+    np.testing.assert_array_equal(p, np.arange(6))
+    src, dst, w = ops.build_coo_host([1], [0], None, 2, 1, False)
+    np.testing.assert_array_equal(w, [1.0, 1.0])
+
+
+def test_spmm_plan_covers_long_rows():
+    ptr = np.array([0, 3, 3, 700, 705, 1400], np.int32)
+    lr, lcp, cb, ce = ops.spmm_plan_host(ptr, 128, 256)
+    np.testing.assert_array_equal(lr, [2, 4])
+    np.testing.assert_array_equal(lcp, [0, 3, 6])
+    np.testing.assert_array_equal(cb, [3, 259, 515, 705, 961, 1217])
+    np.testing.assert_array_equal(ce, [259, 515, 700, 961, 1217, 1400])
+
+
+def test_mt19937_stream_is_cpythons():
+    st = np.zeros(625, np.uint32)
+    for seed in (0, 1, 42, 2 ** 32 + 5, 2 ** 63 + 11):
+        _ffi.call("rk_mt_seed_host", _ffi.ptr(st), ctypes.c_uint64(seed))
+        random.seed(seed)
+        version, internal, _ = random.getstate()
+        np.testing.assert_array_equal(st, np.array(internal, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("R", [1, 3, 6, 20])
+def test_negative_sampler_bit_exact_vs_python_random(R):
+    rng = np.random.default_rng(R)
+    U, I = 40, 57
+    users = rng.integers(0, U, 300)
+    items = rng.integers(0, I, 300)
+    # user 0 has touched everything but 2 items, user 1 everything (no candidates)
+    users = np.concatenate([users, np.zeros(I - 2, np.int64), np.ones(I, np.int64)])
+    items = np.concatenate([items, np.arange(I - 2), np.arange(I)])
+    p, it = build_user_csr(users, items, U)
+    uii = {}
+    for u, i in zip(users, items):
+        uii.setdefault(int(u), set()).add(int(i))
+    batch = np.concatenate([rng.integers(0, U, 200), [0, 1, 0, 1]])
+    s = NegativeSampler(p, it, I, seed=123, neg_ratio=R)
+    random.seed(123)
+    for _ in range(3):
+        ranks, neg = s.sample(batch)
+        want = np.asarray(sampler_oracle.generate_negative_samples(batch, uii, set(range(I)), R))
+        np.testing.assert_array_equal(neg, want)
+    # the generator state stays in lock-step with CPython's
+    np.testing.assert_array_equal(s.state, np.array(random.getstate()[1], dtype=np.uint32))
+
+
+def test_batches_bit_exact_vs_reference_loader(golden):
+    """Shuffle order, batch contents and negative items equal what the reference's
+    GraphDataLoader produced (num_workers=0) for two epochs and three settings."""
+    z = golden("loader_batches.npz")
+    U, I = int(z["n_users"]), int(z["n_items"])
+    p, it = build_user_csr(z["users"], z["items"], U)          # positives over the FULL table
+    label = z["label"]
+    tr = label == 0
+    for tag, R, bs in (("r1_b64", 1, 64), ("r3_b50", 3, 50), ("r8_b32", 8, 32)):
+        np.testing.assert_array_equal(z["users"][tr], z[f"{tag}/train_users"])
+        random.seed(42), np.random.seed(42), torch.manual_seed(42)
+        sampler = NegativeSampler(p, it, I, seed=42, neg_ratio=R)
+        loader = TrainBatchLoader(z["users"][tr], z["items"][tr], z["rating"][tr], bs, sampler)
+        for e in range(2):
+            batches = list(loader)
+            assert len(batches) == int(z[f"{tag}/e{e}/n_batches"]) == len(loader)
+            cat = lambda k: np.concatenate([b[k].numpy() for b in batches])
+            np.testing.assert_array_equal(cat("user_ids"), z[f"{tag}/e{e}/user_ids"])
+            np.testing.assert_array_equal(cat("item_ids"), z[f"{tag}/e{e}/item_ids"])
+            np.testing.assert_array_equal(cat("ratings"), z[f"{tag}/e{e}/ratings"])
+            np.testing.assert_array_equal(cat("neg_items"), z[f"{tag}/e{e}/neg_items"])
