@@ -68,14 +68,17 @@ int rk_csr_from_coo_host(const int32_t *key_host, const int32_t *other_host,
                          int64_t nnz, int32_t n_nodes, int32_t *ptr_host,
                          int32_t *idx_host, int32_t *eid_host);
 
-/* Row binning for the SpMM kernels: rows longer than long_thresh are cut into
- * chunks of `chunk` edges.  First call with the output pointers NULL to get
- * the counts, then with buffers of n_long, n_long+1, n_chunks, n_chunks. */
+/* Row binning for the SpMM kernels (see rk_spmm_plan below): rows with more
+ * than long_thresh edges are cut into chunks of 2048 edges, one workgroup each;
+ * rows longer than one chunk get one partial-row slot per chunk.  First call
+ * with the six array pointers NULL to get the counts, then with buffers of
+ * n_chunks (x4), n_multi and n_multi+1 entries. */
 int rk_spmm_plan_host(const int32_t *ptr_host, int32_t n_rows,
-                      int32_t long_thresh, int32_t chunk, int32_t *n_long_out,
-                      int32_t *n_chunks_out, int32_t *long_rows_host,
-                      int32_t *long_chunk_ptr_host, int32_t *chunk_begin_host,
-                      int32_t *chunk_end_host);
+                      int32_t long_thresh, int32_t *n_chunks_out,
+                      int32_t *n_multi_out, int32_t *n_slots_out,
+                      int32_t *chunk_row_host, int32_t *chunk_begin_host,
+                      int32_t *chunk_end_host, int32_t *chunk_slot_host,
+                      int32_t *multi_rows_host, int32_t *multi_slot_ptr_host);
 
 /* ---- G2: symmetric normalisation (device) ------------------------------ */
 /* Replaces GraphConstructor._normalize_graph/_norm, graph_constructor.py:158-187:
@@ -101,14 +104,17 @@ int rk_gather_f32(const float *src, const int32_t *idx, int64_t n, float *out,
 
 /* ---- G3: propagation h <- A h (device) ---------------------------------- */
 typedef struct rk_spmm_plan {
-  int32_t long_thresh;            /* rows with more edges are "long"        */
-  int32_t n_long;                 /* number of long rows                    */
-  const int32_t *long_rows;       /* [n_long] row ids                       */
-  const int32_t *long_chunk_ptr;  /* [n_long+1] chunk range of each long row */
-  int32_t n_chunks;
-  const int32_t *chunk_begin;     /* [n_chunks] first edge of the chunk     */
-  const int32_t *chunk_end;       /* [n_chunks] one past its last edge      */
-  float *partial;                 /* [n_chunks * D] scratch, caller-owned   */
+  int32_t long_thresh;            /* rows with more edges go to the long tier */
+  int32_t n_chunks;               /* long-tier workgroups                     */
+  const int32_t *chunk_row;       /* [n_chunks] destination row               */
+  const int32_t *chunk_begin;     /* [n_chunks] first edge of the chunk       */
+  const int32_t *chunk_end;       /* [n_chunks] one past its last edge        */
+  const int32_t *chunk_slot;      /* [n_chunks] partial slot, -1 = whole row  */
+  int32_t n_multi;                /* rows cut into more than one chunk        */
+  const int32_t *multi_rows;      /* [n_multi] their row ids                  */
+  const int32_t *multi_slot_ptr;  /* [n_multi+1] slot range of each           */
+  int32_t n_slots;
+  float *partial;                 /* [n_slots * D] scratch, caller-owned      */
 } rk_spmm_plan;
 
 /* Replaces update_all(fn.u_mul_e('h','weight','m'), fn.sum('m','h')),

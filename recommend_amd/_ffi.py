@@ -32,12 +32,15 @@ class RkError(RuntimeError):
 class SpmmPlan(Structure):
     _fields_ = [
         ("long_thresh", c_int32),
-        ("n_long", c_int32),
-        ("long_rows", c_void_p),
-        ("long_chunk_ptr", c_void_p),
         ("n_chunks", c_int32),
+        ("chunk_row", c_void_p),
         ("chunk_begin", c_void_p),
         ("chunk_end", c_void_p),
+        ("chunk_slot", c_void_p),
+        ("n_multi", c_int32),
+        ("multi_rows", c_void_p),
+        ("multi_slot_ptr", c_void_p),
+        ("n_slots", c_int32),
         ("partial", c_void_p),
     ]
 
@@ -50,8 +53,8 @@ SIGNATURES = {
     "rk_device_count": (c_int32, []),
     "rk_build_coo_host": (c_int32, [P, P, P, c_int64, c_int32, c_int32, c_int32, P, P, P]),
     "rk_csr_from_coo_host": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
-    "rk_spmm_plan_host": (c_int32, [P, c_int32, c_int32, c_int32, POINTER(c_int32),
-                                    POINTER(c_int32), P, P, P, P]),
+    "rk_spmm_plan_host": (c_int32, [P, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                    POINTER(c_int32), P, P, P, P, P, P]),
     "rk_sym_normalize_f32": (c_int32, [P, P, P, P, c_int32, P, P, P]),
     "rk_deg_normalize_f32": (c_int32, [P, P, P, c_int32, P, P]),
     "rk_gather_f32": (c_int32, [P, P, c_int64, P, P]),

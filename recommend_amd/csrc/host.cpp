@@ -101,36 +101,6 @@ int rk_csr_from_coo_host(const int32_t *key, const int32_t *other, int64_t nnz,
   return RK_OK;
 }
 
-int rk_spmm_plan_host(const int32_t *ptr, int32_t n_rows, int32_t long_thresh,
-                      int32_t chunk, int32_t *n_long_out, int32_t *n_chunks_out,
-                      int32_t *long_rows, int32_t *long_chunk_ptr,
-                      int32_t *chunk_begin, int32_t *chunk_end) {
-  RK_CHECK_ARG(ptr && n_rows >= 0 && long_thresh > 0 && chunk > 0, "bad plan arguments");
-  RK_CHECK_ARG(n_long_out && n_chunks_out, "null count outputs");
-  int32_t nl = 0, nc = 0;
-  const bool fill = long_rows && long_chunk_ptr && chunk_begin && chunk_end;
-  for (int32_t r = 0; r < n_rows; ++r) {
-    const int32_t b = ptr[r], e = ptr[r + 1];
-    if (e - b <= long_thresh) continue;
-    if (fill) {
-      long_rows[nl] = r;
-      long_chunk_ptr[nl] = nc;
-    }
-    for (int32_t c = b; c < e; c += chunk) {
-      if (fill) {
-        chunk_begin[nc] = c;
-        chunk_end[nc] = std::min(c + chunk, e);
-      }
-      ++nc;
-    }
-    ++nl;
-  }
-  if (fill) long_chunk_ptr[nl] = nc;
-  *n_long_out = nl;
-  *n_chunks_out = nc;
-  return RK_OK;
-}
-
 // ---------------------------------------------------------------- N -------
 // MT19937 exactly as CPython's _randommodule.c uses it.
 namespace {

@@ -61,21 +61,22 @@ def csr_from_coo_host(key, other, n_nodes):
     return p, idx, eid
 
 
-def spmm_plan_host(rowptr, long_thresh, chunk):
-    """Row binning of a CSR: (long_rows, long_chunk_ptr, chunk_begin, chunk_end) numpy int32."""
+def spmm_plan_host(rowptr, long_thresh):
+    """Row binning of a CSR -> dict of numpy int32 arrays (see rk_spmm_plan)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     n_rows = rowptr.shape[0] - 1
-    nl, nc = c_int32(0), c_int32(0)
+    nc, nm, ns = c_int32(0), c_int32(0), c_int32(0)
     _ffi.call("rk_spmm_plan_host", ptr(rowptr), c_int32(n_rows), c_int32(long_thresh),
-              c_int32(chunk), ctypes.byref(nl), ctypes.byref(nc), None, None, None, None)
-    long_rows = np.empty(max(nl.value, 1), np.int32)
-    lcp = np.empty(nl.value + 1, np.int32)
-    cb = np.empty(max(nc.value, 1), np.int32)
-    ce = np.empty(max(nc.value, 1), np.int32)
+              ctypes.byref(nc), ctypes.byref(nm), ctypes.byref(ns), None, None, None, None, None, None)
+    arr = {k: np.zeros(max(nc.value, 1), np.int32) for k in ("chunk_row", "chunk_begin", "chunk_end", "chunk_slot")}
+    arr["multi_rows"] = np.zeros(max(nm.value, 1), np.int32)
+    arr["multi_slot_ptr"] = np.zeros(nm.value + 1, np.int32)
     _ffi.call("rk_spmm_plan_host", ptr(rowptr), c_int32(n_rows), c_int32(long_thresh),
-              c_int32(chunk), ctypes.byref(nl), ctypes.byref(nc), ptr(long_rows), ptr(lcp),
-              ptr(cb), ptr(ce))
-    return long_rows[:nl.value], lcp, cb[:nc.value], ce[:nc.value]
+              ctypes.byref(nc), ctypes.byref(nm), ctypes.byref(ns), ptr(arr["chunk_row"]),
+              ptr(arr["chunk_begin"]), ptr(arr["chunk_end"]), ptr(arr["chunk_slot"]),
+              ptr(arr["multi_rows"]), ptr(arr["multi_slot_ptr"]))
+    arr.update(n_chunks=nc.value, n_multi=nm.value, n_slots=ns.value)
+    return arr
 
 
 # --------------------------------------------------------------------------
@@ -85,27 +86,24 @@ class CsrMatrix:
     """One sparse operand on one device: CSR arrays, edge values and the row
     binning the SpMM kernels use.  `eid` maps CSR positions to COO edge ids."""
 
-    LONG_THRESH = 128
-    CHUNK = 256
+    LONG_THRESH = 64
 
     def __init__(self, rowptr, idx, eid, device):
         self.n_rows = int(rowptr.shape[0] - 1)
         self.nnz = int(idx.shape[0])
         self.device = torch.device(device)
-        lr, lcp, cb, ce = spmm_plan_host(rowptr, self.LONG_THRESH, self.CHUNK)
+        pl = spmm_plan_host(rowptr, self.LONG_THRESH)
         # empty arrays are padded to one element so that no NULL pointer reaches the library
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a if len(a) else np.zeros(1, a.dtype))).to(self.device)
         self.rowptr = to(rowptr)
         self.idx = to(idx)
         self.eid = to(eid)
-        self.n_long = int(lr.shape[0])
-        self.n_chunks = int(cb.shape[0])
-        self.long_rows = to(lr) if self.n_long else None
-        self.long_chunk_ptr = to(lcp) if self.n_long else None
-        self.chunk_begin = to(cb) if self.n_long else None
-        self.chunk_end = to(ce) if self.n_long else None
+        self.n_long = self.n_chunks = pl["n_chunks"]
+        self.n_multi, self.n_slots = pl["n_multi"], pl["n_slots"]
+        self._plan_dev = {k: to(pl[k]) for k in ("chunk_row", "chunk_begin", "chunk_end", "chunk_slot",
+                                                 "multi_rows", "multi_slot_ptr")} if self.n_chunks else None
         self.val = None          # fp32 [nnz] in CSR order
-        self._partial = {}       # D -> scratch for long-row chunks
+        self._partial = {}       # D -> scratch for the chunks of multi-chunk rows
 
     def set_values_from_coo(self, w_coo):
         """val[p] = w_coo[eid[p]]"""
@@ -115,15 +113,17 @@ class CsrMatrix:
                   stream_ptr(self.device))
 
     def plan(self, D):
-        if not self.n_long:
+        if not self.n_chunks:
             return None, None
         part = self._partial.get(D)
         if part is None:
-            part = torch.empty(self.n_chunks * D, dtype=torch.float32, device=self.device)
+            part = torch.empty(max(self.n_slots, 1) * D, dtype=torch.float32, device=self.device)
             self._partial[D] = part
-        p = _ffi.SpmmPlan(self.LONG_THRESH, self.n_long, self.long_rows.data_ptr(),
-                          self.long_chunk_ptr.data_ptr(), self.n_chunks,
-                          self.chunk_begin.data_ptr(), self.chunk_end.data_ptr(), part.data_ptr())
+        d = self._plan_dev
+        p = _ffi.SpmmPlan(self.LONG_THRESH, self.n_chunks, d["chunk_row"].data_ptr(),
+                          d["chunk_begin"].data_ptr(), d["chunk_end"].data_ptr(),
+                          d["chunk_slot"].data_ptr(), self.n_multi, d["multi_rows"].data_ptr(),
+                          d["multi_slot_ptr"].data_ptr(), self.n_slots, part.data_ptr())
         return p, part
 
 

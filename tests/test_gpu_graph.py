@@ -58,7 +58,7 @@ def test_normalize_isolated_nodes_without_self_loops():
 
 
 @pytest.mark.parametrize("D", [16, 32, 64, 128, 256])
-@pytest.mark.parametrize("hub", [0, 1500])
+@pytest.mark.parametrize("hub", [0, 1500, 6000])
 def test_spmm_forward_backward_vs_oracle(D, hub):
     U, I, E = 500, 300, 4000
     users, items, ratings = random_graph(U, I, E, D + hub, hub)

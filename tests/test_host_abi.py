@@ -88,12 +88,16 @@ def test_empty_graph_and_no_ratings():
 
 
 def test_spmm_plan_covers_long_rows():
-    ptr = np.array([0, 3, 3, 700, 705, 1400], np.int32)
-    lr, lcp, cb, ce = ops.spmm_plan_host(ptr, 128, 256)
-    np.testing.assert_array_equal(lr, [2, 4])
-    np.testing.assert_array_equal(lcp, [0, 3, 6])
-    np.testing.assert_array_equal(cb, [3, 259, 515, 705, 961, 1217])
-    np.testing.assert_array_equal(ce, [259, 515, 700, 961, 1217, 1400])
+    ptr = np.array([0, 3, 3, 703, 708, 5008], np.int32)       # rows of 3, 0, 700, 5, 4300 edges
+    pl = ops.spmm_plan_host(ptr, 64)
+    assert (pl["n_chunks"], pl["n_multi"], pl["n_slots"]) == (4, 1, 3)
+    np.testing.assert_array_equal(pl["chunk_row"], [2, 4, 4, 4])
+    np.testing.assert_array_equal(pl["chunk_begin"], [3, 708, 2756, 4804])
+    np.testing.assert_array_equal(pl["chunk_end"], [703, 2756, 4804, 5008])
+    np.testing.assert_array_equal(pl["chunk_slot"], [-1, 0, 1, 2])
+    np.testing.assert_array_equal(pl["multi_rows"], [4])
+    np.testing.assert_array_equal(pl["multi_slot_ptr"], [0, 3])
+    assert ops.spmm_plan_host(np.array([0, 2, 5], np.int32), 64)["n_chunks"] == 0
 
 
 def test_mt19937_stream_is_cpythons():
