@@ -145,6 +145,33 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
                     int32_t D, int32_t n_users, float *dW, float *db, void *ws,
                     size_t ws_bytes, void *stream);
 
+/* ---- W2: node-wise 64 -> 64 layers around the hops (device, fp32 MFMA) ---- */
+/* Replaces dropout(active(f(h))) with f = Linear, active = PReLU (one slope) in
+ * agg_func (graph_constructor.py:204), Combine (Combin_Layer.py:26-30: the sum of
+ * two Linears is the X2/W2 pair), MGCN's embedding branch (out_Layer.py:36: R is
+ * the residual added after the dropout) and final_projection + dropout
+ * (Main_Model.py:162-163):
+ *   Y = dropout(prelu(X1 W1^T [+ X2 W2^T] + b1 [+ b2], alpha), p) [+ R]
+ * alpha == NULL: no activation.  p_drop == 0: no dropout.  Dropout keeps element
+ * (row, col) iff a counter hash of (seed, row*D+col) is >= p; survivors are scaled
+ * by 1/(1-p) (same distribution as nn.Dropout, different random stream).
+ * W: D x K (nn.Linear layout).  Built for K = D = 64. */
+int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2,
+                     const float *W2, const float *b1, const float *b2,
+                     const float *alpha, float p_drop, uint64_t seed,
+                     const float *residual, int64_t n_rows, int32_t K, int32_t D,
+                     float *Y, void *stream);
+size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D);
+/* Backward of the single-input layer for upstream gradient G (the residual's
+ * gradient is G itself): recomputes Z = X W^T + b and the dropout mask, writes
+ * dX (may be NULL), dW, db (may be NULL), dalpha (NULL iff alpha is NULL).  A
+ * two-input linear layer is differentiated with one call per input. */
+int rk_dense_bwd_f32(const float *X, const float *W, const float *b,
+                     const float *alpha, float p_drop, uint64_t seed,
+                     const float *G, int64_t n_rows, int32_t K, int32_t D,
+                     float *dX, float *dW, float *db, float *dalpha, void *ws,
+                     size_t ws_bytes, void *stream);
+
 /* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
 /* Replaces GraphDataLoader._generate_negative_samples,
  * data/graph_data_loader.py:355-397, whose random.sample / random.choices calls

@@ -10,6 +10,7 @@
 // it is cut into item slices whose 64 x 128 partial tiles are summed in slice
 // order by a second kernel (deterministic, no float atomics).
 #include "common.h"
+#include "slab_reduce.h"
 
 namespace {
 
@@ -197,28 +198,6 @@ __global__ __launch_bounds__(256) void proj_dw_kernel(const float *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab,
-                                                          int32_t n_slices, int64_t n,
-                                                          float *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.0f;
-  for (int32_t k = 0; k < n_slices; ++k) s += slab[(int64_t)k * n + i];
-  out[i] = s;
-}
-
-// column sums of a rows x D matrix: stage 1 sums row blocks, stage 2 = slab_reduce
-constexpr int CS_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ M, int64_t rows,
-                                                     int32_t D, float *__restrict__ part) {
-  const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
-  for (int32_t c = threadIdx.x; c < D; c += 256) {
-    float s = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) s += M[r * D + c];
-    part[(int64_t)blockIdx.x * D + c] = s;
-  }
-}
-
 inline int dw_slices(int32_t n_items, int32_t F, int32_t D) {
   const int64_t tiles = rk::ceil_div(F, WF) * rk::ceil_div(D, 64);
   int64_t s = rk::ceil_div(1024, tiles);
@@ -253,9 +232,11 @@ int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, 
 
 size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F, int32_t D) {
   if (n_items < 0 || n_users < 0 || F <= 0 || D <= 0) return 0;
-  // dW slabs; the bias partials reuse the same buffer afterwards
-  const size_t slab = (size_t)dw_slices(n_items, F, D) * D * F * sizeof(float);
-  const size_t bias = (size_t)rk::ceil_div((int64_t)n_items + n_users, CS_ROWS) * D * sizeof(float);
+  // dW slabs + segment sums; the bias partials reuse the same buffer afterwards
+  const int slices = dw_slices(n_items, F, D);
+  const size_t slab = ((size_t)slices * D * F + rk::slab_tmp_floats(slices, (int64_t)D * F)) * sizeof(float);
+  const int64_t nb = rk::ceil_div((int64_t)n_items + n_users, rk::kColsumRows);
+  const size_t bias = ((size_t)nb * D + rk::slab_tmp_floats((int32_t)nb, D)) * sizeof(float);
   return slab > bias ? slab : bias;
 }
 
@@ -275,21 +256,21 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
     dim3 grid((unsigned)rk::ceil_div(F, WF), (unsigned)rk::ceil_div(D, 64), (unsigned)slices);
     proj_dw_kernel<<<grid, 256, 0, st>>>(X, n_items, F, dY + (int64_t)n_users * D, D, ips, slab);
     RK_CHECK_LAUNCH("proj_dw_kernel");
-    slab_reduce_kernel<<<(unsigned)rk::ceil_div(nW, 256), 256, 0, st>>>(slab, slices, nW, dW);
-    RK_CHECK_LAUNCH("slab_reduce_kernel");
+    const int rc = rk::slab_reduce(slab, slices, nW, nW, slab + (size_t)slices * nW, dW, st);
+    if (rc != RK_OK) return rc;
   } else {
     RK_CHECK_HIP(hipMemsetAsync(dW, 0, nW * sizeof(float), st));
   }
   if (db) {
     const int64_t rows = (int64_t)n_users + n_items;
-    const int64_t nb = rk::ceil_div(rows, CS_ROWS);
+    const int64_t nb = rk::ceil_div(rows, rk::kColsumRows);
     if (nb == 0) {
       RK_CHECK_HIP(hipMemsetAsync(db, 0, D * sizeof(float), st));
     } else {
-      colsum_kernel<<<(unsigned)nb, 256, 0, st>>>(dY, rows, D, slab);
-      RK_CHECK_LAUNCH("colsum_kernel");
-      slab_reduce_kernel<<<(unsigned)rk::ceil_div(D, 256), 256, 0, st>>>(slab, (int32_t)nb, D, db);
-      RK_CHECK_LAUNCH("slab_reduce_kernel");
+      rk::colsum_stage1<<<(unsigned)nb, 256, 0, st>>>(dY, rows, D, slab);
+      RK_CHECK_LAUNCH("colsum_stage1");
+      const int rc = rk::slab_reduce(slab, (int32_t)nb, D, D, slab + (size_t)nb * D, db, st);
+      if (rc != RK_OK) return rc;
     }
   }
   return RK_OK;

@@ -1,0 +1,108 @@
+// Deterministic reduction of per-workgroup partial results ("slabs").
+//
+// slab[p * stride + e], p = 0..n_part-1, is summed over p for every element e in
+// a fixed order: the partial range is cut into SEG contiguous segments; inside a
+// segment four lanes per element stride the partials and are folded through LDS;
+// the segment sums are then added in segment order.  No float atomics, so the
+// result does not depend on scheduling.  Used for weight/bias gradients.
+#pragma once
+#include "common.h"
+
+namespace rk {
+namespace {
+
+constexpr int kSlabMaxSeg = 16;
+
+__global__ __launch_bounds__(256) void slab_reduce_stage1(const float *__restrict__ slab,
+                                                          int32_t n_part, int64_t stride,
+                                                          int64_t n_elem, int32_t n_seg,
+                                                          float *__restrict__ tmp) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, q = tid >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + (tid & 63);
+  const int32_t seg = blockIdx.y;
+  const int32_t lo = (int32_t)((int64_t)n_part * seg / n_seg);
+  const int32_t hi = (int32_t)((int64_t)n_part * (seg + 1) / n_seg);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n_elem) {
+    int32_t p = lo + q;
+    for (; p + 12 < hi; p += 16) {
+      s0 += slab[(int64_t)p * stride + e];
+      s1 += slab[(int64_t)(p + 4) * stride + e];
+      s2 += slab[(int64_t)(p + 8) * stride + e];
+      s3 += slab[(int64_t)(p + 12) * stride + e];
+    }
+    for (; p < hi; p += 4) s0 += slab[(int64_t)p * stride + e];
+  }
+  red[q][tid & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && e < n_elem)
+    tmp[(int64_t)seg * n_elem + e] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_stage2(const float *__restrict__ tmp,
+                                                          int32_t n_seg, int64_t n_elem,
+                                                          float *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elem) return;
+  float s = 0.0f;
+  for (int32_t k = 0; k < n_seg; ++k) s += tmp[(int64_t)k * n_elem + e];
+  out[e] = s;
+}
+
+inline int slab_segments(int32_t n_part) {
+  int s = n_part / 32;
+  return s < 1 ? 1 : (s > kSlabMaxSeg ? kSlabMaxSeg : s);
+}
+
+// scratch floats needed besides the slab itself
+inline size_t slab_tmp_floats(int32_t n_part, int64_t n_elem) {
+  return (size_t)slab_segments(n_part) * (size_t)n_elem;
+}
+
+// out[e] = sum_p slab[p*stride + e]; tmp holds slab_tmp_floats(n_part, n_elem) floats
+inline int slab_reduce(const float *slab, int32_t n_part, int64_t stride, int64_t n_elem, float *tmp,
+                       float *out, hipStream_t st) {
+  if (n_elem <= 0) return RK_OK;
+  const int n_seg = slab_segments(n_part);
+  dim3 grid((unsigned)ceil_div(n_elem, 64), (unsigned)n_seg);
+  slab_reduce_stage1<<<grid, 256, 0, st>>>(slab, n_part, stride, n_elem, n_seg, n_seg == 1 ? out : tmp);
+  RK_CHECK_LAUNCH("slab_reduce_stage1");
+  if (n_seg > 1) {
+    slab_reduce_stage2<<<(unsigned)ceil_div(n_elem, 256), 256, 0, st>>>(tmp, n_seg, n_elem, out);
+    RK_CHECK_LAUNCH("slab_reduce_stage2");
+  }
+  return RK_OK;
+}
+
+// Column sums of a rows x D matrix, stage 1: workgroup b sums rows [b*kColsumRows, ...) into
+// part[b*D + c]; finish with slab_reduce(part, n_blocks, D, D, ...).
+constexpr int kColsumRows = 1024;
+
+__global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ M, int64_t rows,
+                                                     int32_t D, float *__restrict__ part) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, q = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
+  const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
+  for (int32_t c0 = 0; c0 < D; c0 += 64) {
+    const int32_t c = c0 + (tid & 63);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < D) {
+      int64_t r = r0 + q;
+      for (; r + 4 < r1; r += 8) {
+        s0 += M[r * D + c];
+        s1 += M[(r + 4) * D + c];
+      }
+      for (; r < r1; r += 4) s0 += M[r * D + c];
+    }
+    __syncthreads();
+    red[q][tid & 63] = s0 + s1;
+    __syncthreads();
+    if (q == 0 && c < D)
+      part[(int64_t)blockIdx.x * D + c] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+}  // namespace
+}  // namespace rk

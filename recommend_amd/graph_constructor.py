@@ -14,7 +14,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _ffi, ops
+from . import _ffi, fused, ops
 
 
 class DeviceGraph:
@@ -206,7 +206,7 @@ class GraphConstructor:
         fwd, bwd = self._operands()
         h = node_x
         for _ in range(k):
-            h = dropout(active(f(h)))
+            h = fused.linear_act(f, h, active, dropout)   # dropout(active(f(h)))
             h = ops.spmm(fwd, bwd, h)
         return h
 

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import fused, ops
 from .graph_constructor import GraphConstructor
 
 
@@ -60,9 +60,9 @@ class Combine(nn.Module):
         self.active = MyPReLU()
 
     def forward(self, ori_feature_x, feature_x):
-        y1 = self.W_ori_f(ori_feature_x)
-        y2 = self.W_f(feature_x)
-        return self.dropout(self.active(self.W_o(y1 + y2)))
+        # dropout(active(W_o(W_ori_f(x) + W_f(agg_x)))), Combin_Layer.py:26-30
+        y = fused.linear_sum(self.W_ori_f, ori_feature_x, self.W_f, feature_x)
+        return fused.linear_act(self.W_o, y, self.active, self.dropout)
 
 
 class MGCN(nn.Module):
@@ -78,7 +78,8 @@ class MGCN(nn.Module):
         agg_X = self.agg(X, g, k)
         for f in self.combine:
             agg_X = f(X, agg_X)
-        return agg_X + self.dropout(self.active(self.W_o(emb)))
+        # agg_X + dropout(active(W_o(emb))), out_Layer.py:36
+        return fused.linear_act(self.W_o, emb, self.active, self.dropout, residual=agg_X)
 
 
 class TEST(nn.Module):
@@ -89,9 +90,12 @@ class TEST(nn.Module):
 
     def forward(self, g, Xs, embs, ks, alphas):
         modal_features = [self.MGCNs[i](g, Xs[i], embs[i], ks[i]) for i in range(self.modal_num)]
-        modal_features = torch.stack(modal_features, dim=0)
-        new_alphas = torch.softmax(alphas, dim=0).unsqueeze(-1).unsqueeze(-1)
-        return torch.sum(new_alphas * modal_features, dim=0)
+        # sum_m softmax(alphas)_m * F_m (out_Layer.py:52-54) without stacking the modalities
+        new_alphas = torch.softmax(alphas, dim=0)
+        out = modal_features[0] * new_alphas[0]
+        for i in range(1, self.modal_num):
+            out = out + modal_features[i] * new_alphas[i]
+        return out
 
 
 class _ItemProjection(nn.Module):
@@ -209,8 +213,8 @@ class TESTModel(nn.Module):
         self.Xs = [self._project(linear, x, is_item)
                    for linear, x, is_item in zip(self.linears, self.feats, self._feat_is_item)]
         node_embeddings = self.test(g, self.Xs, self.embs, self.ks, self.alphas)
-        node_embeddings = self.final_projection(node_embeddings)
-        node_embeddings = self.dropout(node_embeddings)
+        # dropout(final_projection(.)), Main_Model.py:162-163
+        node_embeddings = fused.linear_act(self.final_projection, node_embeddings, None, self.dropout)
         return {
             "user_embeddings": node_embeddings[: self.num_users],
             "item_embeddings": node_embeddings[self.num_users:],

@@ -6,6 +6,7 @@ arithmetic of the hot path runs in librecommend_amd.so.  Every function here
 requires CUDA(HIP) tensors and raises otherwise.
 """
 import ctypes
+import itertools
 
 import numpy as np
 import torch
@@ -294,6 +295,90 @@ def bpr_gather_dot_sampled(U, I, users, pos, neg_rank, pos_ptr, pos_items, mask=
     """Same loss with negatives resolved in the kernel from per-sample ranks;
     returns (loss, neg_items)."""
     return _Bpr.apply(U, I, users, pos, None, mask, neg_rank, pos_ptr, pos_items, I.shape[0])
+
+
+# --------------------------------------------------------------------------
+# W2: fused node-wise layers  Y = dropout(prelu(X1 W1^T [+ X2 W2^T] + b)) [+ R]
+# --------------------------------------------------------------------------
+_seed_counter = itertools.count(1)
+
+
+def next_dropout_seed():
+    """64-bit seed for one dropout call: torch's seed mixed with a call counter, so a run
+    re-seeded with torch.manual_seed reproduces its masks."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+
+
+def dense_supported(x, weight):
+    return x.is_cuda and x.dim() == 2 and tuple(weight.shape) == (64, 64) and x.shape[1] == 64
+
+
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2, alpha, residual, p, seed):
+        _need_cuda(x1, w1, b1, x2, w2, b2, alpha, residual)
+        if x2 is not None and (alpha is not None or p > 0.0):
+            raise ValueError("the two-input form is linear only (no activation / dropout)")
+        x1, w1 = _f32c(x1), _f32c(w1)
+        b1 = _f32c(b1) if b1 is not None else None
+        if x2 is not None:
+            x2, w2 = _f32c(x2), _f32c(w2)
+            b2 = _f32c(b2) if b2 is not None else None
+        if residual is not None:
+            residual = _f32c(residual)
+        alpha_c = _f32c(alpha) if alpha is not None else None
+        if alpha_c is not None and alpha_c.numel() != 1:
+            raise ValueError("only a single PReLU slope is supported")
+        n, K = x1.shape
+        D = w1.shape[0]
+        y = torch.empty((n, D), dtype=torch.float32, device=x1.device)
+        _ffi.call("rk_dense_fwd_f32", ptr(x1), ptr(w1), ptr(x2), ptr(w2), ptr(b1), ptr(b2), ptr(alpha_c),
+                  c_float(p), _ffi.c_uint64(seed), ptr(residual), c_int64(n), c_int32(K), c_int32(D),
+                  ptr(y), stream_ptr(y.device))
+        ctx.save_for_backward(x1, w1, b1, x2, w2, alpha_c)
+        ctx.p, ctx.seed = p, seed
+        ctx.has = (b1 is not None, b2 is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, w1, b1, x2, w2, alpha = ctx.saved_tensors
+        has_b1, has_b2, has_res = ctx.has
+        g = _f32c(g)
+        n, K = x1.shape
+        D = w1.shape[0]
+        dev = g.device
+        lib = _ffi.load()
+        ws = torch.empty(lib.rk_dense_bwd_ws_bytes(n, K, D) // 4 + 4, dtype=torch.float32, device=dev)
+
+        def run(x, w, b, want_dx, al):
+            dx = torch.empty_like(x) if want_dx else None
+            dw = torch.empty_like(w)
+            db = torch.empty(D, dtype=torch.float32, device=dev)
+            da = torch.empty(1, dtype=torch.float32, device=dev) if al is not None else None
+            _ffi.call("rk_dense_bwd_f32", ptr(x), ptr(w), ptr(b), ptr(al), c_float(ctx.p),
+                      _ffi.c_uint64(ctx.seed), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw),
+                      ptr(db), ptr(da), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(dev))
+            return dx, dw, db, da
+
+        need = ctx.needs_input_grad
+        dx1, dw1, db, da = run(x1, w1, b1, need[0], alpha)
+        dx2 = dw2 = None
+        if x2 is not None:
+            dx2, dw2, _db2, _ = run(x2, w2, None, need[3], None)
+        return (dx1, dw1, db if has_b1 else None, dx2, dw2, db if has_b2 else None,
+                da, g if has_res else None, None, None)
+
+
+def dense(x, weight, bias=None, alpha=None, p=0.0, residual=None, x2=None, weight2=None, bias2=None,
+          seed=None):
+    """Y = dropout(prelu(x W^T [+ x2 W2^T] + b [+ b2], alpha), p) [+ residual] in one kernel
+    (64 -> 64 layers).  alpha None: no activation; p == 0: no dropout."""
+    p = float(p)
+    if seed is None:
+        seed = next_dropout_seed() if p > 0.0 else 0
+    y = _Dense.apply(x, weight, bias, x2, weight2, bias2, alpha, residual, p, int(seed))
+    return y
 
 
 # --------------------------------------------------------------------------

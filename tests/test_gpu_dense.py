@@ -1,0 +1,126 @@
+"""GPU parity: fused node-wise layer (Linear + PReLU + dropout [+ residual], and
+the two-input linear sum) forward and backward against a float64 torch
+restatement of the same composition of nn modules.  Tolerance 1e-5 of scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from recommend_amd import fused, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def make(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 64, generator=g)
+    w = torch.randn(64, 64, generator=g) / 8
+    b = torch.randn(64, generator=g)
+    r = torch.randn(n, 64, generator=g)
+    go = torch.randn(n, 64, generator=g)
+    return x, w, b, r, go
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 130, 1000, 70000])
+@pytest.mark.parametrize("act,res", [(True, False), (True, True), (False, False)])
+def test_dense_forward_backward_no_dropout(n, act, res):
+    x, w, b, r, go = make(n, n)
+    alpha = torch.tensor([0.25])
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    ad = alpha.to(DEV).requires_grad_(True) if act else None
+    rd = r.to(DEV).requires_grad_(True) if res else None
+    y = ops.dense(xd, wd, bd, alpha=ad, residual=rd)
+    y.backward(go.to(DEV))
+    x6, w6, b6 = (t.double().requires_grad_(True) for t in (x, w, b))
+    a6 = alpha.double().requires_grad_(True)
+    r6 = r.double().requires_grad_(True)
+    y6 = F.linear(x6, w6, b6)
+    if act:
+        y6 = F.prelu(y6, a6)
+    if res:
+        y6 = y6 + r6
+    y6.backward(go.double())
+    assert rel(y, y6) <= 1e-5
+    assert rel(xd.grad, x6.grad) <= 1e-5
+    assert rel(wd.grad, w6.grad) <= 1e-5
+    assert rel(bd.grad, b6.grad) <= 1e-5
+    if act:
+        assert rel(ad.grad, a6.grad) <= 1e-5
+    if res:
+        assert torch.equal(rd.grad.cpu(), go)
+
+
+def test_dense_two_input_linear_sum():
+    n = 5000
+    x1, w1, b1, _, go = make(n, 1)
+    x2, w2, b2, _, _ = make(n, 2)
+    t = [v.to(DEV).requires_grad_(True) for v in (x1, w1, b1, x2, w2, b2)]
+    y = ops.dense(t[0], t[1], t[2], x2=t[3], weight2=t[4], bias2=t[5])
+    y.backward(go.to(DEV))
+    d = [v.double().requires_grad_(True) for v in (x1, w1, b1, x2, w2, b2)]
+    y6 = F.linear(d[0], d[1], d[2]) + F.linear(d[3], d[4], d[5])
+    y6.backward(go.double())
+    assert rel(y, y6) <= 1e-5
+    for a, b in zip(t, d):
+        assert rel(a.grad, b.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("act", [True, False])
+def test_dense_dropout_is_consistent_and_unbiased(act):
+    """Dropout uses its own counter hash: check the keep rate, the 1/(1-p) scaling,
+    that forward and backward use the same mask, and seed reproducibility."""
+    n, p = 20000, 0.3
+    x, w, b, _, go = make(n, 7)
+    alpha = torch.tensor([0.25], device=DEV, requires_grad=True) if act else None
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True)
+    y = ops.dense(xd, wd, bd, alpha=alpha, p=p, seed=1234)
+    y2 = ops.dense(xd, wd, bd, alpha=alpha, p=p, seed=1234)
+    y3 = ops.dense(xd, wd, bd, alpha=alpha, p=p, seed=1235)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    full = ops.dense(xd, wd, bd, alpha=alpha)
+    keep = (y != 0) | (full == 0)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 0.005
+    torch.testing.assert_close(y[keep], (full / (1 - p))[keep], rtol=1e-6, atol=1e-7)
+    # rows/columns are not correlated: per-column keep rate is also ~1-p
+    assert float((keep.float().mean(0) - (1 - p)).abs().max()) < 0.02
+    # backward: gradient equals that of the same function with the mask made explicit
+    y.backward(go.to(DEV))
+    mask = keep.double().cpu() / (1 - p)
+    x6, w6, b6 = (t.double().requires_grad_(True) for t in (x, w, b))
+    z6 = F.linear(x6, w6, b6)
+    if act:
+        a6 = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+        z6 = F.prelu(z6, a6)
+    (z6 * mask).backward(go.double())
+    assert rel(xd.grad, x6.grad) <= 1e-5
+    assert rel(wd.grad, w6.grad) <= 1e-5
+    assert rel(bd.grad, b6.grad) <= 1e-5
+    if act:
+        assert rel(alpha.grad, a6.grad) <= 1e-5
+
+
+def test_module_routing_matches_unfused_modules():
+    """fused.linear_act / linear_sum give what the plain nn modules give (eval mode)."""
+    torch.manual_seed(0)
+    lin, lin2 = torch.nn.Linear(64, 64).to(DEV), torch.nn.Linear(64, 64).to(DEV)
+    act, dr = torch.nn.PReLU().to(DEV), torch.nn.Dropout(0.5).eval()
+    x, x2 = torch.randn(777, 64, device=DEV), torch.randn(777, 64, device=DEV)
+    torch.testing.assert_close(fused.linear_act(lin, x, act, dr), dr(act(lin(x))), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fused.linear_act(lin, x, None, dr, residual=x2), x2 + lin(x), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fused.linear_sum(lin, x, lin2, x2), lin(x) + lin2(x2), rtol=1e-5, atol=1e-5)
+    # shapes the kernel is not built for run as plain modules
+    lin3 = torch.nn.Linear(48, 64).to(DEV)
+    x3 = torch.randn(10, 48, device=DEV)
+    assert not fused.can_fuse(lin3, x3)
+    torch.testing.assert_close(fused.linear_act(lin3, x3, act, dr), act(lin3(x3)))
