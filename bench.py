@@ -112,10 +112,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)   # BENCH_BACKEND=gloo rehearsals share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     U, I, E = synth.SHAPES[args.shape]
     D = args.emb_dim
@@ -166,8 +171,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
+        from recommend_amd.dist import all_reduce_tensor
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_tensor(t, dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = 1e3 * elapsed / args.steps
     users_per_s = U * args.steps / elapsed

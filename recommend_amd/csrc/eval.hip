@@ -3,8 +3,8 @@
 // ranking-metric reductions (gfx950).
 //
 // score_topk_kernel.  A workgroup of 4 wavefronts owns 128 users and one slice
-// of the item range.  Item rows are staged 32 at a time through a
-// double-buffered, padded LDS tile shared by the 4 wavefronts; each wavefront
+// of the item range.  Item rows are staged 32 at a time by LDS-DMA into a
+// double-buffered, XOR-swizzled LDS tile shared by the 4 wavefronts; each wavefront
 // multiplies the tile with its 32 users on v_mfma_f32_32x32x2_f32.  With the
 // items on the MFMA rows and the users on the MFMA columns, lane l ends up
 // with 16 scores that all belong to user (l & 31): the whole top-K state of a
@@ -28,7 +28,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int TI = 32;     // items per LDS tile (MFMA rows)
 constexpr int UPB = 128;   // users per workgroup (4 wavefronts x 32)
 constexpr int QS = 8;      // queue slots per lane
-constexpr int ROWPAD = 4;  // floats of padding per LDS tile row (bank spread)
 constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
 __host__ __device__ inline int kpad_for(int K) { return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
@@ -77,8 +76,9 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
     int32_t nsplit, int32_t item_id_offset, float *__restrict__ part_s,
     int32_t *__restrict__ part_id) {
   constexpr int D = 64 * DC;
-  constexpr int ROW = D + ROWPAD;
-  __shared__ __attribute__((aligned(16))) float tile[2][TI * ROW];
+  // item tile: TI rows of D floats, unpadded; the 16-byte chunks of a row are XOR-swizzled with
+  // the row number so that the b128 fragment reads of 16 different rows hit 16 different slots
+  __shared__ __attribute__((aligned(1024))) float tile[2][TI * D];
   __shared__ float q_s[4][QS][kWave];
   __shared__ int32_t q_id[4][QS][kWave];
 
@@ -133,25 +133,23 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
   float thr = -INFINITY;
   int qc = 0;
 
-  // tile staging: 32 rows x D floats = 8*DC float4 per row, 2*DC float4 per thread
-  constexpr int F4_PER_ROW = D / 4;
-  constexpr int LOADS = TI * F4_PER_ROW / 256;
-  float4 stage[LOADS];
-  auto load_tile = [&](int32_t t) {
+  // Tile staging by LDS-DMA: one wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly from
+  // per-lane global addresses, so no staging registers are live across the MFMA / selection phase.
+  constexpr int CPR = D / 4;        // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece
+  constexpr int PPW = TI / RPP / 4; // pieces per wavefront
+  auto issue_tile = [&](int32_t t, int buf) {
 #pragma unroll
-    for (int j = 0; j < LOADS; ++j) {
-      const int e = tid + 256 * j;
-      const int32_t item = t * TI + e / F4_PER_ROW;
-      stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (item < n_items)
-        stage[j] = *reinterpret_cast<const float4 *>(Iemb + (int64_t)item * D + 4 * (e % F4_PER_ROW));
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < LOADS; ++j) {
-      const int e = tid + 256 * j;
-      *reinterpret_cast<float4 *>(&tile[buf][(e / F4_PER_ROW) * ROW + 4 * (e % F4_PER_ROW)]) = stage[j];
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave * PPW + j;
+      const int r = piece * RPP + lane / CPR;
+      const int slot = lane % CPR;
+      const int chunk = (slot & ~15) | ((slot & 15) ^ (r & 15));
+      // rows past the end of the table re-read the last item; their scores are discarded below
+      const int32_t item = min(t * TI + r, n_items - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void *)(Iemb + (int64_t)item * D + 4 * chunk),
+          (__attribute__((address_space(3))) void *)(&tile[buf][piece * 256]), 16, 0, 0);
     }
   };
   auto flush = [&]() {
@@ -167,15 +165,13 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
     thr = list.s[KPAD - 1];
   };
 
-  if (t_lo < t_hi) {
-    load_tile(t_lo);
-    store_tile(0);
-  }
+  if (t_lo < t_hi) issue_tile(t_lo, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int32_t t = t_lo; t < t_hi; ++t) {
     const int buf = (t - t_lo) & 1;
-    if (t + 1 < t_hi) load_tile(t + 1);
+    if (t + 1 < t_hi) issue_tile(t + 1, buf ^ 1);   // lands during this tile's MFMA + selection
 
     floatx16 acc;
 #pragma unroll
@@ -185,8 +181,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
       float afrag[32];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float4 v =
-            *reinterpret_cast<const float4 *>(&tile[buf][col * ROW + 64 * c + 32 * half + 4 * q]);
+        const int slot = 16 * c + ((8 * half + q) ^ (col & 15));
+        const float4 v = *reinterpret_cast<const float4 *>(&tile[buf][col * D + 4 * slot]);
         afrag[4 * q + 0] = v.x;
         afrag[4 * q + 1] = v.y;
         afrag[4 * q + 2] = v.z;
@@ -231,7 +227,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
       }
     }
 
-    if (t + 1 < t_hi) store_tile(buf ^ 1);
+    // the DMA of the next tile must have landed before any wavefront reads it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   flush();

@@ -21,6 +21,33 @@ import torch.distributed as dist
 from .evaluator import METRIC_ORDER, pairs_to_csr, restrict_csr, target_to_csr, _pad64
 
 
+def _via_host(group):
+    """gloo rehearsals (several ranks sharing one GPU) exchange through host memory;
+    with nccl (= RCCL) the device tensors go over xGMI directly."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_gather_tensor(t, world, group=None):
+    if _via_host(group) and t.is_cuda:
+        c = t.cpu()
+        out = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(out, c, group=group)
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return out
+
+
+def all_reduce_tensor(t, op=dist.ReduceOp.SUM, group=None):
+    if _via_host(group) and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+        return t
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def item_range(n_items, rank, world):
     return (n_items * rank) // world, (n_items * (rank + 1)) // world
 
@@ -75,10 +102,8 @@ class ShardedRankingEvaluator:
         st = self._state(user_embeddings.device)
         s, ids = self.local_topk(user_embeddings, item_embeddings_full, kmax)
         # one exchange step: every rank's [U, K] lists
-        gs = [torch.empty_like(s) for _ in range(self.world)]
-        gi = [torch.empty_like(ids) for _ in range(self.world)]
-        dist.all_gather(gs, s.contiguous(), group=self.group)
-        dist.all_gather(gi, ids.contiguous(), group=self.group)
+        gs = all_gather_tensor(s.contiguous(), self.world, self.group)
+        gi = all_gather_tensor(ids.contiguous(), self.world, self.group)
         sl = slice(self.u_lo, self.u_hi)
         cand_s = torch.stack([g[sl] for g in gs], dim=1).contiguous()     # [u, world, K]
         cand_i = torch.stack([g[sl] for g in gi], dim=1).contiguous()
@@ -89,7 +114,7 @@ class ShardedRankingEvaluator:
             self.last_ids = mi
             _out, sums = self.compute.rank_metrics(mi, st["tgt_ptr"], st["tgt_items"], self.k_list,
                                                    mean_denominator=self.n_users, return_sums=True)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        all_reduce_tensor(sums, dist.ReduceOp.SUM, self.group)
         table = (sums / float(self.n_users)).to(torch.float32).cpu()
         out = {}
         for ki, k in enumerate(self.k_list):
