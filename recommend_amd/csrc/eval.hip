@@ -2,43 +2,47 @@
 // top-K that never writes the user x item score matrix, a list merge, and the
 // ranking-metric reductions (gfx950).
 //
-// score_topk_kernel.  A workgroup of 4 wavefronts owns 128 users and one slice
-// of the item range.  Item rows are staged 32 at a time by LDS-DMA into a
-// double-buffered, XOR-swizzled LDS tile shared by the 4 wavefronts; each wavefront
-// multiplies the tile with its 32 users on v_mfma_f32_32x32x2_f32.  With the
-// items on the MFMA rows and the users on the MFMA columns, lane l ends up
-// with 16 scores that all belong to user (l & 31): the whole top-K state of a
-// user lives in two lanes' registers (a sorted list of KPAD scores and ids)
-// and no cross-lane traffic is needed while streaming.  A score enters a lane's
-// list only if it beats the lane's current KPAD-th best, which is rare after
-// the first tiles, so candidates are parked in a small per-lane LDS queue and
-// the (expensive, fully unrolled) sorted insertion runs only when some lane's
-// queue is nearly full, with all lanes inserting together.
+// score_topk_kernel.  Every wavefront works alone: it owns 64 users and walks one
+// slice of the item range in tiles of 32 items.  It stages its own tiles by LDS-DMA
+// (global_load_lds, 1 KiB per instruction) into a private double buffer whose 16-byte
+// chunks are XOR-swizzled with the row number (conflict-free b128 fragment reads), so
+// the main loop has no workgroup barrier: the only wait on a tile is the wavefront's
+// own vmcnt.  Per tile it runs two chains of v_mfma_f32_32x32x2_f32 (items on the MFMA
+// rows, users 0-31 and users 32-63 on the columns).  A 32x32 result leaves each user's
+// 32 scores split over lanes l and l+32; one v_permlane32_swap per register pair
+// gives lane l all 32 scores of user l and lane l+32 all 32 scores of user 32+l.  So
+// the whole top-K state of a user (a sorted list of KPAD scores and ids) lives in ONE
+// lane's registers, and there is one partial list per user and item slice.
 //
-// Because every lane sees its items in ascending id order and insertion uses a
-// strict '>', equal scores keep the lower item id first; the final merge of
-// the per-lane / per-slice lists orders by (score desc, id asc) explicitly.
+// A score enters a lane's list only if it beats the lane's current KPAD-th best.
+// Candidates are parked in an 8-deep per-lane LDS queue and the unrolled sorted
+// insertion runs only when some lane's queue is nearly full, all lanes inserting
+// together.  Every lane sees its items in ascending id order and insertion uses a
+// strict '>', so equal scores keep the lower item id first; the merge of the
+// per-slice lists orders by (score desc, id asc) explicitly.
 #include "common.h"
 
 namespace {
 
 using rk::kWave;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 
 constexpr int TI = 32;     // items per LDS tile (MFMA rows)
-constexpr int UPB = 128;   // users per workgroup (4 wavefronts x 32)
+constexpr int UPW = 64;    // users per wavefront
+constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
 constexpr int QS = 8;      // queue slots per lane
 constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
 __host__ __device__ inline int kpad_for(int K) { return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
 
-// number of item slices per user tile: enough workgroups to fill 256 CUs a few
-// times over, a power of two so that slices map onto XCDs (blockIdx % 8)
+// item slices per user tile: enough workgroups to fill 256 CUs several times, a power
+// of two so that slices map onto XCDs (blockIdx % 8) and stay in that XCD's L2
 inline int choose_nsplit(int n_users, int n_items) {
   const int utiles = (int)rk::ceil_div(n_users, UPB);
   const int tiles = (int)rk::ceil_div(n_items, TI);
   int ns = 1;
-  while (utiles * ns < 2048 && ns < 16 && tiles / (ns * 2) >= 4) ns *= 2;  // 2*ns*32 <= MERGE_MAX
+  while (utiles * ns < 2048 && ns < 16 && tiles / (ns * 2) >= 4) ns *= 2;  // ns*32 <= MERGE_MAX
   return ns;
 }
 
@@ -69,16 +73,17 @@ struct LaneList {
 };
 
 template <int KPAD, int DC>
-__global__ __launch_bounds__(256) void score_topk_kernel(
+__global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
     const float *__restrict__ Uemb, int32_t n_users,
     const float *__restrict__ Iemb, int32_t n_items,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
     int32_t nsplit, int32_t item_id_offset, float *__restrict__ part_s,
     int32_t *__restrict__ part_id) {
   constexpr int D = 64 * DC;
-  // item tile: TI rows of D floats, unpadded; the 16-byte chunks of a row are XOR-swizzled with
-  // the row number so that the b128 fragment reads of 16 different rows hit 16 different slots
-  __shared__ __attribute__((aligned(1024))) float tile[2][TI * D];
+  // two separate arrays, not one indexed by a buffer number: the compiler then knows that a DMA
+  // into one cannot alias a read of the other and does not wait for the prefetch before reading
+  __shared__ __attribute__((aligned(1024))) float tile0[4][TI * D];
+  __shared__ __attribute__((aligned(1024))) float tile1[4][TI * D];
   __shared__ float q_s[4][QS][kWave];
   __shared__ int32_t q_id[4][QS][kWave];
 
@@ -87,26 +92,29 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
   const int col = lane & 31, half = lane >> 5;
   const int32_t split = blockIdx.x % nsplit;
   const int32_t utile = blockIdx.x / nsplit;
-  const int32_t user = utile * UPB + wave * 32 + col;
+  const int32_t ubase = utile * UPB + wave * UPW;
+  const int32_t user = ubase + lane;          // the user whose list this lane keeps
   const bool user_ok = user < n_users;
 
   const int32_t tiles_total = (n_items + TI - 1) / TI;
   const int32_t t_lo = (int32_t)((int64_t)tiles_total * split / nsplit);
   const int32_t t_hi = (int32_t)((int64_t)tiles_total * (split + 1) / nsplit);
 
-  // user fragment: B[k][j=col], this lane holds k = 64c + 32*half + m
-  float bfrag[DC][32];
+  // user fragments B[k][j = col]: chain A multiplies users ubase+col, chain B users ubase+32+col;
+  // this lane holds k = 64c + 32*half + m
+  float bfa[DC][32], bfb[DC][32];
 #pragma unroll
   for (int c = 0; c < DC; ++c)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (user_ok)
-        v = *reinterpret_cast<const float4 *>(Uemb + (int64_t)user * D + 64 * c + 32 * half + 4 * q);
-      bfrag[c][4 * q + 0] = v.x;
-      bfrag[c][4 * q + 1] = v.y;
-      bfrag[c][4 * q + 2] = v.z;
-      bfrag[c][4 * q + 3] = v.w;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      const int64_t off = 64 * c + 32 * half + 4 * q;
+      if (ubase + col < n_users)
+        va = *reinterpret_cast<const float4 *>(Uemb + (int64_t)(ubase + col) * D + off);
+      if (ubase + 32 + col < n_users)
+        vb = *reinterpret_cast<const float4 *>(Uemb + (int64_t)(ubase + 32 + col) * D + off);
+      bfa[c][4 * q + 0] = va.x; bfa[c][4 * q + 1] = va.y; bfa[c][4 * q + 2] = va.z; bfa[c][4 * q + 3] = va.w;
+      bfb[c][4 * q + 0] = vb.x; bfb[c][4 * q + 1] = vb.y; bfb[c][4 * q + 2] = vb.z; bfb[c][4 * q + 3] = vb.w;
     }
 
   // train-mask cursor of this lane's user (item ids ascending)
@@ -114,8 +122,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
   if (mask_ptr && user_ok) {
     mcur = mask_ptr[user];
     mend = mask_ptr[user + 1];
-    // skip entries in front of this slice
-    int32_t lo = mcur, hi = mend;
+    int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
     const int32_t first = t_lo * TI;
     while (lo < hi) {
       const int32_t mid = (lo + hi) >> 1;
@@ -134,22 +141,21 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
   int qc = 0;
 
   // Tile staging by LDS-DMA: one wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly from
-  // per-lane global addresses, so no staging registers are live across the MFMA / selection phase.
-  constexpr int CPR = D / 4;        // 16-byte chunks per row
-  constexpr int RPP = 64 / CPR;     // rows per 1-KiB piece
-  constexpr int PPW = TI / RPP / 4; // pieces per wavefront
-  auto issue_tile = [&](int32_t t, int buf) {
+  // per-lane global addresses; slot s of row r holds chunk s ^ (r & 15) of that item's embedding.
+  constexpr int CPR = D / 4;     // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;  // rows per 1-KiB piece
+  constexpr int PIECES = TI / RPP;
+  auto issue_tile = [&](int32_t t, float *dst) {
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const int piece = wave * PPW + j;
-      const int r = piece * RPP + lane / CPR;
+    for (int p = 0; p < PIECES; ++p) {
+      const int r = p * RPP + lane / CPR;
       const int slot = lane % CPR;
       const int chunk = (slot & ~15) | ((slot & 15) ^ (r & 15));
       // rows past the end of the table re-read the last item; their scores are discarded below
       const int32_t item = min(t * TI + r, n_items - 1);
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void *)(Iemb + (int64_t)item * D + 4 * chunk),
-          (__attribute__((address_space(3))) void *)(&tile[buf][piece * 256]), 16, 0, 0);
+          (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
     }
   };
   auto flush = [&]() {
@@ -164,78 +170,108 @@ __global__ __launch_bounds__(256) void score_topk_kernel(
     qc = 0;
     thr = list.s[KPAD - 1];
   };
+  // one score of this lane's user: mask, range check, threshold test, park
+  auto consider = [&](float v, int row, int32_t item0, uint32_t mbits) {
+    if ((mbits >> row) & 1u) v = kMasked;
+    if (v > thr) {
+      q_s[wave][qc][lane] = v;
+      q_id[wave][qc][lane] = item0 + row;
+      ++qc;
+    }
+  };
 
-  if (t_lo < t_hi) issue_tile(t_lo, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // one tile: prefetch the next one into `nxt`, score and select from `cur`
+  auto process_tile = [&](int32_t t, const float *cur, float *nxt) {
+    if (t + 1 < t_hi) issue_tile(t + 1, nxt);   // lands during this tile's MFMA + selection
 
-  for (int32_t t = t_lo; t < t_hi; ++t) {
-    const int buf = (t - t_lo) & 1;
-    if (t + 1 < t_hi) issue_tile(t + 1, buf ^ 1);   // lands during this tile's MFMA + selection
-
-    floatx16 acc;
+    floatx16 acc_a, acc_b;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) {
+      acc_a[r] = 0.0f;
+      acc_b[r] = 0.0f;
+    }
 #pragma unroll
     for (int c = 0; c < DC; ++c) {
       float afrag[32];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int slot = 16 * c + ((8 * half + q) ^ (col & 15));
-        const float4 v = *reinterpret_cast<const float4 *>(&tile[buf][col * D + 4 * slot]);
+        const float4 v = *reinterpret_cast<const float4 *>(cur + col * D + 4 * slot);
         afrag[4 * q + 0] = v.x;
         afrag[4 * q + 1] = v.y;
         afrag[4 * q + 2] = v.z;
         afrag[4 * q + 3] = v.w;
       }
 #pragma unroll
-      for (int m = 0; m < 32; ++m)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfrag[c][m], acc, 0, 0, 0);
+      for (int m = 0; m < 32; ++m) {
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfa[c][m], acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfb[c][m], acc_b, 0, 0, 0);
+      }
     }
+
+    // Lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in acc_b.
+    // After the swap every lane holds, for ITS user (ubase + lane), rows (r&3)+8*(r>>2) in lo[r]
+    // and rows 4+(r&3)+8*(r>>2) in hi[r].
+    // The swap is written as inline assembly: the compiler's builtin returns its first result for
+    // both halves.  The s_nop pair covers the 18 wait states between the last MFMA pass and a
+    // VALU read of its result, which the compiler does not insert in front of inline assembly.
+    // (the accumulators are operands of the s_nop statement so that it stays behind the MFMAs)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a), "+v"(acc_b));
+    float lo[16], hi[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      lo[r] = acc_a[r];
+      hi[r] = acc_b[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
 
     const int32_t item0 = t * TI;
     // rows past the end of the item table never rank
     if (item0 + TI > n_items) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (item0 + (r & 3) + 8 * (r >> 2) + 4 * half >= n_items) acc[r] = -INFINITY;
+      for (int r = 0; r < 16; ++r) {
+        if (item0 + (r & 3) + 8 * (r >> 2) >= n_items) lo[r] = -INFINITY;
+        if (item0 + 4 + (r & 3) + 8 * (r >> 2) >= n_items) hi[r] = -INFINITY;
+      }
     }
     // training interactions of this user inside the tile get the mask score
+    uint32_t mbits = 0;
     if (__any(next_m < item0 + TI)) {
-      uint32_t mbits = 0;
       while (next_m < item0 + TI) {
-        const int32_t rel = next_m - item0;
-        if (((rel >> 2) & 1) == half) mbits |= 1u << (((rel >> 3) << 2) | (rel & 3));
+        mbits |= 1u << (next_m - item0);
         ++mcur;
         next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if ((mbits >> r) & 1u) acc[r] = kMasked;
     }
-    // park candidates; insert when a queue could overflow in the next 4 steps
+    // park candidates in ascending item order; insert when a queue could overflow in 4 more steps
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = acc[r];
-      if (v > thr) {
-        q_s[wave][qc][lane] = v;
-        q_id[wave][qc][lane] = item0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        ++qc;
-      }
-      if ((r & 3) == 3) {
-        if (__any(qc > QS - 4)) flush();
-      }
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) consider(lo[4 * g + i], 8 * g + i, item0, mbits);
+      if (__any(qc > QS - 4)) flush();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) consider(hi[4 * g + i], 8 * g + 4 + i, item0, mbits);
+      if (__any(qc > QS - 4)) flush();
     }
 
-    // the DMA of the next tile must have landed before any wavefront reads it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // The DMA of the next tile must have landed before this wavefront reads it.  The wait is the
+    // builtin (vmcnt(0), other counters untouched), not inline assembly: the compiler's own
+    // wait-count bookkeeping sees it and does not add a second, earlier wait in the next tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  };
+
+  if (t_lo < t_hi) issue_tile(t_lo, tile0[wave]);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int32_t t = t_lo; t < t_hi; t += 2) {
+    process_tile(t, tile0[wave], tile1[wave]);
+    if (t + 1 < t_hi) process_tile(t + 1, tile1[wave], tile0[wave]);
   }
   flush();
 
   if (user_ok) {
-    const int32_t P = 2 * nsplit;
-    const int64_t base = ((int64_t)user * P + split * 2 + half) * KPAD;
+    const int64_t base = ((int64_t)user * nsplit + split) * KPAD;
 #pragma unroll
     for (int j = 0; j < KPAD; ++j) {
       part_s[base + j] = list.s[j];
@@ -397,7 +433,7 @@ size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32
   (void)D;
   if (n_users <= 0 || n_items <= 0 || K <= 0 || K > 32) return 0;
   const int nsplit = choose_nsplit(n_users, n_items);
-  return (size_t)n_users * 2 * nsplit * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
+  return (size_t)n_users * nsplit * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
 }
 
 int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, int32_t P,
@@ -432,7 +468,7 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
   const int kp = kpad_for(K);
   const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
   float *ps = (float *)ws;
-  int32_t *pi = (int32_t *)(ps + (size_t)n_users * 2 * nsplit * kp);
+  int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kp);
   int rc;
   switch (kp) {
     case 8: rc = launch_score_topk<8>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
@@ -441,7 +477,7 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
     default: rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
   }
   if (rc != RK_OK) return rc;
-  return rk_topk_merge_f32(ps, pi, n_users, 2 * nsplit, kp, K, out_scores, out_ids, stream);
+  return rk_topk_merge_f32(ps, pi, n_users, nsplit, kp, K, out_scores, out_ids, stream);
 }
 
 size_t rk_rank_metrics_ws_bytes(int32_t n_users, int32_t nk) {
