@@ -93,10 +93,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RkError(RK_ERR_NODEV, f"{LIB_PATH} is missing: run `python -m recommend_amd.build` "
+    # RECOMMEND_AMD_LIB names another build of the same C ABI (kernel experiments)
+    path = os.environ.get("RECOMMEND_AMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise RkError(RK_ERR_NODEV, f"{path} is missing: run `python -m recommend_amd.build` "
                       "(or __graft_entry__.build()) first; there is no CPU fallback")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = restype

@@ -36,14 +36,38 @@ constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
 __host__ __device__ inline int kpad_for(int K) { return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
 
-// item slices per user tile: enough workgroups to fill 256 CUs several times, a power
-// of two so that slices map onto XCDs (blockIdx % 8) and stay in that XCD's L2
+// Item slices per user tile.  Every slice restarts its lists from nothing and pays the K*ln(n/K)
+// insertions of a streaming top-K again, so fewer slices are cheaper; what slices buy is a grid
+// that fills the chip evenly.  The estimate below is launch rounds (two workgroups fit a CU)
+// times the work per round, with 4 % of a slice's time charged per extra slice.
+inline int cu_count() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
 inline int choose_nsplit(int n_users, int n_items) {
-  const int utiles = (int)rk::ceil_div(n_users, UPB);
-  const int tiles = (int)rk::ceil_div(n_items, TI);
-  int ns = 1;
-  while (utiles * ns < 2048 && ns < 16 && tiles / (ns * 2) >= 4) ns *= 2;  // ns*32 <= MERGE_MAX
-  return ns;
+  const int64_t utiles = rk::ceil_div(n_users, UPB);
+  const int64_t tiles = rk::ceil_div(n_items, TI);
+  const int64_t slots = 2 * (int64_t)cu_count();
+  int best = 1;
+  double best_cost = 0.0;
+  for (int ns = 1; ns <= 16; ++ns) {  // ns * 32 <= MERGE_MAX
+    if (ns > 1 && tiles / ns < 4) break;
+    const int64_t rounds = rk::ceil_div(utiles * ns, slots);
+    const double cost = (double)rounds / ns * (1.0 + 0.04 * ns);
+    if (ns == 1 || cost < best_cost * 0.999) {
+      best = ns;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 template <int KPAD>
@@ -57,18 +81,20 @@ struct LaneList {
       id[j] = -1;
     }
   }
-  // sorted insertion; a no-op for lanes whose v does not beat the last entry
+  // Sorted insertion; a no-op for lanes whose v does not beat the last entry.  With
+  // s[j-1] >= s[j], the new s[j] is the median of (s[j-1], s[j], v): one v_med3_f32.  The ids
+  // follow the same three cases through the strict compares, so equal scores stay in arrival order.
   __device__ __forceinline__ void insert(float v, int32_t vid) {
     bool c_hi = v > s[KPAD - 1];
 #pragma unroll
     for (int j = KPAD - 1; j >= 1; --j) {
       const bool c_lo = v > s[j - 1];
-      s[j] = c_lo ? s[j - 1] : (c_hi ? v : s[j]);
       id[j] = c_lo ? id[j - 1] : (c_hi ? vid : id[j]);
+      s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
       c_hi = c_lo;
     }
-    s[0] = c_hi ? v : s[0];
     id[0] = c_hi ? vid : id[0];
+    s[0] = fmaxf(s[0], v);
   }
 };
 
@@ -170,14 +196,22 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
     qc = 0;
     thr = list.s[KPAD - 1];
   };
-  // one score of this lane's user: mask, range check, threshold test, park
-  auto consider = [&](float v, int row, int32_t item0, uint32_t mbits) {
-    if ((mbits >> row) & 1u) v = kMasked;
-    if (v > thr) {
-      q_s[wave][qc][lane] = v;
-      q_id[wave][qc][lane] = item0 + row;
-      ++qc;
+  // Four scores of this lane's user (ascending item ids).  Late in the stream hardly any score
+  // beats its lane's threshold, so the wavefront first asks whether any lane has a candidate at
+  // all; only then are the four scores parked, branch free: the store always happens and the
+  // slot advances only for a candidate.
+  auto consider4 = [&](float v0, float v1, float v2, float v3, int32_t id0) {
+    const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    if (!__any(m > thr)) return;
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      q_s[wave][qc][lane] = v[i];
+      q_id[wave][qc][lane] = id0 + i;
+      qc += v[i] > thr ? 1 : 0;
     }
+    // a queue holds QS entries: insert when some lane could overflow within the next 4 scores
+    if (__any(qc > QS - 4)) flush();
   };
 
   // one tile: prefetch the next one into `nxt`, score and select from `cur`
@@ -237,23 +271,23 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
       }
     }
     // training interactions of this user inside the tile get the mask score
-    uint32_t mbits = 0;
     if (__any(next_m < item0 + TI)) {
+      uint32_t mbits = 0;
       while (next_m < item0 + TI) {
         mbits |= 1u << (next_m - item0);
         ++mcur;
         next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((mbits >> ((r & 3) + 8 * (r >> 2))) & 1u) lo[r] = kMasked;
+        if ((mbits >> (4 + (r & 3) + 8 * (r >> 2))) & 1u) hi[r] = kMasked;
+      }
     }
-    // park candidates in ascending item order; insert when a queue could overflow in 4 more steps
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) consider(lo[4 * g + i], 8 * g + i, item0, mbits);
-      if (__any(qc > QS - 4)) flush();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) consider(hi[4 * g + i], 8 * g + 4 + i, item0, mbits);
-      if (__any(qc > QS - 4)) flush();
+      consider4(lo[4 * g], lo[4 * g + 1], lo[4 * g + 2], lo[4 * g + 3], item0 + 8 * g);
+      consider4(hi[4 * g], hi[4 * g + 1], hi[4 * g + 2], hi[4 * g + 3], item0 + 8 * g + 4);
     }
 
     // The DMA of the next tile must have landed before this wavefront reads it.  The wait is the
