@@ -34,7 +34,9 @@ constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
 constexpr int QS = 8;      // queue slots per lane
 constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
-__host__ __device__ inline int kpad_for(int K) { return K <= 8 ? 8 : K <= 16 ? 16 : K <= 24 ? 24 : 32; }
+// list length the kernel is compiled for: K rounded up to a multiple of 4 (an insertion costs one
+// step per list entry, and a longer list also lowers the threshold that filters candidates)
+__host__ __device__ inline int kpad_for(int K) { return K <= 4 ? 4 : (K + 3) / 4 * 4; }
 
 // Item slices per user tile.  Every slice restarts its lists from nothing and pays the K*ln(n/K)
 // insertions of a streaming top-K again, so fewer slices are cheaper; what slices buy is a grid
@@ -99,7 +101,7 @@ struct LaneList {
 };
 
 template <int KPAD, int DC>
-__global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
+__global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_topk_kernel(
     const float *__restrict__ Uemb, int32_t n_users,
     const float *__restrict__ Iemb, int32_t n_items,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
   // into one cannot alias a read of the other and does not wait for the prefetch before reading
   __shared__ __attribute__((aligned(1024))) float tile0[4][TI * D];
   __shared__ __attribute__((aligned(1024))) float tile1[4][TI * D];
-  __shared__ float q_s[4][QS][kWave];
-  __shared__ int32_t q_id[4][QS][kWave];
+  // candidate queues: [wave][0] scores, [wave][1] item ids (one array, so that a score and its
+  // id, a fixed distance apart, go out in one ds_write2)
+  __shared__ uint32_t queue[4][2][QS][kWave];
 
   const int tid = threadIdx.x;
   const int wave = tid / kWave, lane = tid % kWave;
@@ -171,16 +174,33 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
   constexpr int CPR = D / 4;     // 16-byte chunks per row
   constexpr int RPP = 64 / CPR;  // rows per 1-KiB piece
   constexpr int PIECES = TI / RPP;
+  // A full tile is one contiguous block of the table: the per-lane byte offset of piece p is a
+  // loop-invariant pattern XOR a per-piece constant (rows p*RPP + l with l < RPP never carry into
+  // the bits that p*RPP sets), so a piece costs one XOR besides the DMA instruction itself.
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  uint32_t lane_off = (uint32_t)(l_row * D * 4 + (((l_slot & ~15) | ((l_slot & 15) ^ l_row)) * 16));
   auto issue_tile = [&](int32_t t, float *dst) {
+    asm volatile("" : "+v"(lane_off));  // keep the per-piece offsets from being hoisted into registers
+    if ((t + 1) * TI <= n_items) {
+      const char *tile_base = reinterpret_cast<const char *>(Iemb + (int64_t)t * TI * D);
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        const uint32_t off = (lane_off ^ (uint32_t)(((p * RPP) & 15) * 16)) + (uint32_t)(p * 1024);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(tile_base + off),
+            (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+      }
+      return;
+    }
+    // the last, partial tile: rows past the end of the table re-read the last item (their scores
+    // are discarded after the multiplication); same offset pattern, row clamped per lane
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-      const int r = p * RPP + lane / CPR;
-      const int slot = lane % CPR;
-      const int chunk = (slot & ~15) | ((slot & 15) ^ (r & 15));
-      // rows past the end of the table re-read the last item; their scores are discarded below
-      const int32_t item = min(t * TI + r, n_items - 1);
+      const uint32_t off = lane_off ^ (uint32_t)(((p * RPP) & 15) * 16);
+      const int32_t item = min(t * TI + p * RPP + (int32_t)(off / (D * 4)), n_items - 1);
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(Iemb + (int64_t)item * D + 4 * chunk),
+          (const __attribute__((address_space(1))) void *)(
+              reinterpret_cast<const char *>(Iemb + (int64_t)item * D) + (off & (D * 4 - 1))),
           (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
     }
   };
@@ -189,8 +209,8 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
     for (int q = 0; q < QS; ++q) {
       const bool has = q < qc;
       if (!__any(has)) break;
-      const float v = has ? q_s[wave][q][lane] : -INFINITY;
-      const int32_t vid = q_id[wave][q][lane];
+      const float v = has ? __uint_as_float(queue[wave][0][q][lane]) : -INFINITY;
+      const int32_t vid = (int32_t)queue[wave][1][q][lane];
       list.insert(v, vid);
     }
     qc = 0;
@@ -206,17 +226,19 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      q_s[wave][qc][lane] = v[i];
-      q_id[wave][qc][lane] = id0 + i;
+      queue[wave][0][qc][lane] = __float_as_uint(v[i]);
+      queue[wave][1][qc][lane] = (uint32_t)(id0 + i);
       qc += v[i] > thr ? 1 : 0;
     }
     // a queue holds QS entries: insert when some lane could overflow within the next 4 scores
     if (__any(qc > QS - 4)) flush();
   };
 
+  uint32_t frag_off = (uint32_t)(col * D * 4 + ((8 * half) ^ (col & 15)) * 16);
   // one tile: prefetch the next one into `nxt`, score and select from `cur`
   auto process_tile = [&](int32_t t, const float *cur, float *nxt) {
     if (t + 1 < t_hi) issue_tile(t + 1, nxt);   // lands during this tile's MFMA + selection
+    asm volatile("" : "+v"(frag_off));  // as for lane_off: eight hoisted addresses cost eight registers
 
     floatx16 acc_a, acc_b;
 #pragma unroll
@@ -229,8 +251,10 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
       float afrag[32];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int slot = 16 * c + ((8 * half + q) ^ (col & 15));
-        const float4 v = *reinterpret_cast<const float4 *>(cur + col * D + 4 * slot);
+        // slot 16c + ((8*half + q) ^ (col & 15)) of row col; q < 8 only touches bits the other
+        // terms leave alone, so the eight addresses are one per-lane value XOR q*16
+        const float4 v = *reinterpret_cast<const float4 *>(
+            reinterpret_cast<const char *>(cur) + ((frag_off ^ (uint32_t)(q * 16)) + (uint32_t)(c * 256)));
         afrag[4 * q + 0] = v.x;
         afrag[4 * q + 1] = v.y;
         afrag[4 * q + 2] = v.z;
@@ -280,8 +304,11 @@ __global__ __launch_bounds__(256, DC == 1 ? 2 : 1) void score_topk_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if ((mbits >> ((r & 3) + 8 * (r >> 2))) & 1u) lo[r] = kMasked;
-        if ((mbits >> (4 + (r & 3) + 8 * (r >> 2))) & 1u) hi[r] = kMasked;
+        // sign-extended bit (0 or all ones) selects between the score and the mask score
+        const uint32_t ml = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, (r & 3) + 8 * (r >> 2), 1);
+        const uint32_t mh = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, 4 + (r & 3) + 8 * (r >> 2), 1);
+        lo[r] = __uint_as_float((ml & __float_as_uint(kMasked)) | (~ml & __float_as_uint(lo[r])));
+        hi[r] = __uint_as_float((mh & __float_as_uint(kMasked)) | (~mh & __float_as_uint(hi[r])));
       }
     }
 #pragma unroll
@@ -505,9 +532,13 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
   int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kp);
   int rc;
   switch (kp) {
+    case 4: rc = launch_score_topk<4>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
     case 8: rc = launch_score_topk<8>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    case 12: rc = launch_score_topk<12>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
     case 16: rc = launch_score_topk<16>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    case 20: rc = launch_score_topk<20>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
     case 24: rc = launch_score_topk<24>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
+    case 28: rc = launch_score_topk<28>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
     default: rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
   }
   if (rc != RK_OK) return rc;

@@ -12,14 +12,24 @@ from recommend_amd import build as B
 
 OUT = os.path.join(ROOT, "tools", "_variants")
 
-OCC1 = ("__launch_bounds__(256, DC == 1 ? 2 : 1)", "__launch_bounds__(256, 1)")
-FAST = "    if (!__any(m > thr)) return;\n"
+# s_memtime stamps and event counts of one wavefront, printed by a few wavefronts
+STAMP = [
+    ("  LaneList<KPAD> list;\n", "  uint64_t st_sel = 0, st_flush = 0, st_score = 0; int n_slow = 0, n_flush = 0, n_rounds = 0;\n  const uint64_t st0 = __builtin_readcyclecounter();\n  LaneList<KPAD> list;\n"),
+    ("      list.insert(v, vid);\n", "      list.insert(v, vid);\n      ++n_rounds;\n"),
+    ("    if (!__any(m > thr)) return false;\n", "    if (!__any(m > thr)) return false;\n    ++n_slow;\n"),
+    ("      if (full) flush();\n", "      if (full) { const uint64_t f0 = __builtin_readcyclecounter(); flush(); st_flush += __builtin_readcyclecounter() - f0; ++n_flush; }\n"),
+    ("    int g_next = 0;\n", "    const uint64_t c3 = __builtin_readcyclecounter();\n    int g_next = 0;\n"),
+    ("    } while (g_next < 8);\n", "    } while (g_next < 8);\n    st_sel += __builtin_readcyclecounter() - c3;\n"),
+    ("    if ((t - t_lo) & 1)\n", "    const uint64_t c0 = __builtin_readcyclecounter();\n    if ((t - t_lo) & 1)\n"),
+    ("    const int32_t item0 = t * TI;\n    // rows past", "    st_score += __builtin_readcyclecounter() - c0;\n    const int32_t item0 = t * TI;\n    // rows past"),
+    ("  flush();\n\n  if (user_ok) {", "  flush();\n  if (lane == 0 && wave == 1 && blockIdx.x % 701 == 3)\n"
+     "    printf(\"blk %d tiles %d total %llu score %llu sel %llu flush %llu n_slow %d n_flush %d n_rounds %d\\n\", (int)blockIdx.x, (int)(t_hi - t_lo),\n"
+     "           (unsigned long long)(__builtin_readcyclecounter() - st0), (unsigned long long)st_score, (unsigned long long)st_sel,\n"
+     "           (unsigned long long)st_flush, n_slow, n_flush, n_rounds);\n\n  if (user_ok) {"),
+]
 VARIANTS = {
     "base": [],
-    "occ1": [OCC1],
-    "nofast": [(FAST, "")],
-    "ns4": [("  return best;\n}", "  return 4;\n}")],
-    "ns1": [("  return best;\n}", "  return 1;\n}")],
+    "stamp": STAMP,
 }
 
 
@@ -54,6 +64,9 @@ def run():
         env = dict(os.environ, RECOMMEND_AMD_LIB=os.path.join(OUT, f"librk_{name}.so"))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eval_probe.py")] + sys.argv[2:],
                            env=env, capture_output=True, text=True, timeout=300)
+        for l in r.stdout.splitlines():
+            if l.startswith("blk"):
+                print("   ", l)
         line = [l for l in r.stdout.splitlines() if l.startswith("score_topk")]
         print(f"{name:16s} {line[-1] if line else r.stderr[-300:]}", flush=True)
 
