@@ -216,6 +216,33 @@ int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
                    const float *loss_out, const float *gout, float *dU,
                    float *dI, void *stream);
 
+/* ---- L2: the other pairwise losses over the same gather-dot --------------- */
+/* Same arguments as rk_bpr_fwd_f32 / rk_bpr_bwd_f32 plus `mode`:
+ *   RK_LOSS_BPR          mean(-logsigmoid(x))                 (= rk_bpr_*)
+ *   RK_LOSS_LOG_SIGMOID  mean(-log(sigmoid(x))), the two-step form of mmgcn_loss,
+ *                        evalue/loss.py:153-173 (= model/Main_Model.py:672-692), and of the
+ *                        SGrec loss, model/Main_Model.py:902-928
+ *   RK_LOSS_INFO_BPR     mean_b( logsumexp([pos_b, neg_b,*]) - pos_b ), the softmax
+ *                        cross-entropy with the positive as class 0 of
+ *                        compute_info_bpr_loss, evalue/loss.py:95-117 (mask must be NULL;
+ *                        x_out then holds the negatives' log-probabilities). */
+#define RK_LOSS_BPR 0
+#define RK_LOSS_LOG_SIGMOID 1
+#define RK_LOSS_INFO_BPR 2
+int rk_rank_loss_fwd_f32(const float *U, const float *I, int32_t D,
+                         const int64_t *users, const int64_t *pos, int64_t *neg,
+                         int64_t B, int32_t R, const float *mask,
+                         const int32_t *neg_rank, const int32_t *pos_ptr,
+                         const int32_t *pos_items, int32_t n_items, int32_t mode,
+                         float *x_out, float *loss_out, void *ws, size_t ws_bytes,
+                         void *stream);
+int rk_rank_loss_bwd_f32(const float *U, const float *I, int32_t D,
+                         const int64_t *users, const int64_t *pos,
+                         const int64_t *neg, int64_t B, int32_t R,
+                         const float *mask, const float *x, const float *loss_out,
+                         const float *gout, int32_t mode, float *dU, float *dI,
+                         void *stream);
+
 /* Score-level form: bpr_loss(pos_scores[B], neg_scores[B,R], mask),
  * evalue/loss.py:7-28, for callers that computed the scores themselves.
  * ws as rk_bpr_ws_bytes(B, R). */

@@ -74,6 +74,9 @@ SIGNATURES = {
     "rk_bpr_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32,
                                  P, P, P, c_size_t, P]),
     "rk_bpr_bwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, P, P, P]),
+    "rk_rank_loss_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32, c_int32,
+                                       P, P, P, c_size_t, P]),
+    "rk_rank_loss_bwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32, P, P, P]),
     "rk_bpr_scores_fwd_f32": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, c_size_t, P]),
     "rk_bpr_scores_bwd_f32": (c_int32, [P, P, P, P, c_int64, c_int32, P, P, P]),
     "rk_score_topk_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),

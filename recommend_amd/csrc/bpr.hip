@@ -1,5 +1,9 @@
-// BPR gather-dot loss, forward and backward, with the negative-item lookup
-// folded into the forward kernel (gfx950).
+// Pairwise ranking losses on gathered dot products, forward and backward, with the
+// negative-item lookup folded into the forward kernel (gfx950).  The per-sample term is
+// selected by `mode`: BPR -logsigmoid(x) (evalue/loss.py:7-28), -log(sigmoid(x)) as
+// mmgcn_loss / the SGrec loss spell it (evalue/loss.py:153-173, Main_Model.py:902-928), or
+// the softmax cross-entropy over [pos, negatives] of compute_info_bpr_loss
+// (evalue/loss.py:95-117).
 //
 // One group of 16 lanes owns one training sample; every lane walks the
 // embedding row in float4 steps (stride 16 float4), so D = 64 is exactly one
@@ -52,12 +56,23 @@ __device__ __forceinline__ float neg_logsigmoid(float x) {
   return fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
 }
 
+constexpr int kModeLogSigmoid = 0;     // RK_LOSS_BPR
+constexpr int kModeLogOfSigmoid = 1;   // RK_LOSS_LOG_SIGMOID
+constexpr int kModeSoftmaxCE = 2;      // RK_LOSS_INFO_BPR
+
+// per-pair term of modes 0 and 1; mode 1 keeps the reference's two-step form, which
+// saturates (sigmoid underflows to 0, the log gives inf) where logsigmoid does not
+__device__ __forceinline__ float pair_term(float x, int mode) {
+  if (mode == kModeLogOfSigmoid) return -logf(1.0f / (1.0f + expf(-x)));
+  return neg_logsigmoid(x);
+}
+
 __global__ __launch_bounds__(256) void bpr_fwd_kernel(
     const float *__restrict__ U, const float *__restrict__ I, int32_t D,
     const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
     int64_t *__restrict__ neg, int64_t B, int32_t R,
     const float *__restrict__ mask, const int32_t *__restrict__ neg_rank,
-    const int32_t *__restrict__ pos_ptr, const int32_t *__restrict__ pos_items,
+    const int32_t *__restrict__ pos_ptr, const int32_t *__restrict__ pos_items, int mode,
     float *__restrict__ x_out, float *__restrict__ part) {
   __shared__ float s_loss[SPB], s_den[SPB];
   const int sub = threadIdx.x % GL, grp = threadIdx.x / GL;
@@ -69,6 +84,7 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(
     const float4 *pu = reinterpret_cast<const float4 *>(U + u * D);
     const float4 *pi = reinterpret_cast<const float4 *>(I + pos[s] * D);
     const float ps = dot_rows(pu, pi, d4, sub);
+    float mx = ps, se = 1.0f;   // running max and sum of exp(. - max) over [pos, negatives]
     for (int32_t r = 0; r < R; ++r) {
       int64_t n;
       if (neg_rank) {
@@ -84,8 +100,24 @@ __global__ __launch_bounds__(256) void bpr_fwd_kernel(
       const float x = ps - dot_rows(pu, ni, d4, sub);
       const float m = mask ? mask[s * R + r] : 1.0f;
       if (sub == 0) x_out[s * R + r] = x;
-      loss += neg_logsigmoid(x) * m;
-      den += m;
+      if (mode == kModeSoftmaxCE) {
+        const float ns = ps - x;
+        const float nm = fmaxf(mx, ns);
+        se = se * expf(mx - nm) + expf(ns - nm);
+        mx = nm;
+      } else {
+        loss += pair_term(x, mode) * m;
+        den += m;
+      }
+    }
+    if (mode == kModeSoftmaxCE) {
+      // cross entropy with the positive as class 0: logsumexp - pos; the backward pass needs the
+      // negatives' log-probabilities, which replace the saved differences
+      const float lse = mx + logf(se);
+      loss = lse - ps;
+      den = 1.0f;
+      if (sub == 0)
+        for (int32_t r = 0; r < R; ++r) x_out[s * R + r] = (ps - x_out[s * R + r]) - lse;
     }
   }
   if (sub == 0) {
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
     const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
     const int64_t *__restrict__ neg, int64_t B, int32_t R,
     const float *__restrict__ mask, const float *__restrict__ x,
-    const float *__restrict__ loss_out, const float *__restrict__ gout,
+    const float *__restrict__ loss_out, const float *__restrict__ gout, int mode,
     float *__restrict__ dU, float *__restrict__ dI) {
   const int sub = threadIdx.x % GL;
   const int64_t s = (int64_t)blockIdx.x * SPB + threadIdx.x / GL;
@@ -156,8 +188,9 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
   for (int32_t r = 0; r < R; ++r) {
     const float xv = x[s * R + r];
     const float m = mask ? mask[s * R + r] : 1.0f;
-    // d(-logsigmoid(x))/dx = -sigmoid(-x) = -1/(1+exp(x))
-    const float g = -scale * m / (1.0f + expf(xv));
+    // d(-logsigmoid(x))/dx = -sigmoid(-x) = -1/(1+exp(x)); for the cross entropy the saved value
+    // is log p_r and d loss / d neg_r = p_r, d loss / d pos = -sum_r p_r
+    const float g = mode == kModeSoftmaxCE ? -scale * expf(xv) : -scale * m / (1.0f + expf(xv));
     const int64_t n = neg[s * R + r];
     const float4 *ni = reinterpret_cast<const float4 *>(I + n * D);
     // x = <pu,pi> - <pu,ni>:  d/dni = -g*pu ; d/dpu += g*(pi - ni)
@@ -255,12 +288,14 @@ size_t rk_bpr_ws_bytes(int64_t B, int32_t R) {
   return (size_t)(2 * rk::ceil_div(B, SPB) + 2) * sizeof(float);
 }
 
-int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
-                   const int64_t *users, const int64_t *pos, int64_t *neg,
-                   int64_t B, int32_t R, const float *mask,
-                   const int32_t *neg_rank, const int32_t *pos_ptr,
-                   const int32_t *pos_items, int32_t n_items, float *x_out,
-                   float *loss_out, void *ws, size_t ws_bytes, void *stream) {
+int rk_rank_loss_fwd_f32(const float *U, const float *I, int32_t D,
+                         const int64_t *users, const int64_t *pos, int64_t *neg,
+                         int64_t B, int32_t R, const float *mask,
+                         const int32_t *neg_rank, const int32_t *pos_ptr,
+                         const int32_t *pos_items, int32_t n_items, int32_t mode, float *x_out,
+                         float *loss_out, void *ws, size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(mode >= 0 && mode <= 2, "unknown loss mode");
+  RK_CHECK_ARG(mode != kModeSoftmaxCE || mask == nullptr, "the cross-entropy form takes no mask");
   // train/graph_trainer.py:262-263 raises on an empty batch
   RK_CHECK_ARG(B > 0 && R > 0, "batch error, recive null user or item or neg_items");
   RK_CHECK_ARG(U && I && users && pos && neg && x_out && loss_out && ws, "null pointer");
@@ -272,10 +307,35 @@ int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
   const int32_t nb = (int32_t)rk::ceil_div(B, SPB);
   float *part = (float *)ws;
   bpr_fwd_kernel<<<nb, 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask, neg_rank, pos_ptr,
-                                      pos_items, x_out, part);
+                                      pos_items, mode, x_out, part);
   RK_CHECK_LAUNCH("bpr_fwd_kernel");
   bpr_final_kernel<<<1, rk::kWave, 0, st>>>(part, nb, mask != nullptr, loss_out);
   RK_CHECK_LAUNCH("bpr_final_kernel");
+  return RK_OK;
+}
+
+int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
+                   const int64_t *users, const int64_t *pos, int64_t *neg,
+                   int64_t B, int32_t R, const float *mask,
+                   const int32_t *neg_rank, const int32_t *pos_ptr,
+                   const int32_t *pos_items, int32_t n_items, float *x_out,
+                   float *loss_out, void *ws, size_t ws_bytes, void *stream) {
+  return rk_rank_loss_fwd_f32(U, I, D, users, pos, neg, B, R, mask, neg_rank, pos_ptr, pos_items,
+                              n_items, kModeLogSigmoid, x_out, loss_out, ws, ws_bytes, stream);
+}
+
+int rk_rank_loss_bwd_f32(const float *U, const float *I, int32_t D,
+                         const int64_t *users, const int64_t *pos, const int64_t *neg,
+                         int64_t B, int32_t R, const float *mask, const float *x,
+                         const float *loss_out, const float *gout, int32_t mode, float *dU,
+                         float *dI, void *stream) {
+  RK_CHECK_ARG(mode >= 0 && mode <= 2, "unknown loss mode");
+  RK_CHECK_ARG(B > 0 && R > 0, "empty batch");
+  RK_CHECK_ARG(U && I && users && pos && neg && x && loss_out && gout && dU && dI, "null pointer");
+  RK_CHECK_ARG(D > 0 && D % 4 == 0, "embedding width must be a multiple of 4");
+  bpr_bwd_kernel<<<(int32_t)rk::ceil_div(B, SPB), 256, 0, (hipStream_t)stream>>>(
+      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dU, dI);
+  RK_CHECK_LAUNCH("bpr_bwd_kernel");
   return RK_OK;
 }
 
@@ -284,13 +344,8 @@ int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
                    int64_t B, int32_t R, const float *mask, const float *x,
                    const float *loss_out, const float *gout, float *dU,
                    float *dI, void *stream) {
-  RK_CHECK_ARG(B > 0 && R > 0, "empty batch");
-  RK_CHECK_ARG(U && I && users && pos && neg && x && loss_out && gout && dU && dI, "null pointer");
-  RK_CHECK_ARG(D > 0 && D % 4 == 0, "embedding width must be a multiple of 4");
-  bpr_bwd_kernel<<<(int32_t)rk::ceil_div(B, SPB), 256, 0, (hipStream_t)stream>>>(
-      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, dU, dI);
-  RK_CHECK_LAUNCH("bpr_bwd_kernel");
-  return RK_OK;
+  return rk_rank_loss_bwd_f32(U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout,
+                              kModeLogSigmoid, dU, dI, stream);
 }
 
 }  // extern "C"

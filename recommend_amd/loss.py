@@ -80,3 +80,56 @@ def gather_dot_bpr_loss(outputs, batch):
 
 
 __all__ = ["bpr_loss", "gather_dot_bpr_loss"]
+
+
+def mmgcn_loss(outputs, batch):
+    """mmgcn_loss (evalue/loss.py:153-173, = model/Main_Model.py:672-692): one negative per
+    sample, -mean(log(sigmoid(pos - neg))) in the reference's two-step form, plus the
+    regulariser that the reference multiplies by zero (kept: it propagates NaN/inf like there)."""
+    empty = torch.tensor([], dtype=torch.long)
+    batch_users = batch.get("user_ids", empty)
+    pos_items = batch.get("item_ids", empty)
+    neg_items = batch.get("neg_items", empty).reshape(-1)
+    user_h = outputs["user_embeddings"]
+    item_h = outputs["item_embeddings"]
+    id_embedding = outputs["id_embeddings"]
+    dev = user_h.device
+    batch_users, pos_items, neg_items = batch_users.to(dev), pos_items.to(dev), neg_items.to(dev)
+    loss = ops.bpr_gather_dot(user_h, item_h, batch_users, pos_items, neg_items.reshape(-1, 1),
+                              mode=ops.LOSS_LOG_SIGMOID)
+    user_tensor = batch_users.repeat_interleave(2)
+    item_tensor = torch.stack((pos_items, neg_items)).t().contiguous().view(-1)
+    reg_embedding_loss = (id_embedding[user_tensor] ** 2 + id_embedding[item_tensor] ** 2).mean()
+    reg_embedding_loss = reg_embedding_loss + (outputs["pres"] ** 2).mean()
+    return loss + 0 * reg_embedding_loss
+
+
+def compute_info_bpr_loss(a_embeddings, b_embeddings, pos_edges, neg_items, reduction="mean",
+                          hard_negs=None):
+    """compute_info_bpr_loss (evalue/loss.py:95-117): softmax cross-entropy over
+    [<a, b_pos>, <a, b_neg_1>, ...] with the positive as the target class."""
+    if reduction != "mean":
+        raise ValueError("only reduction='mean' is built")
+    if isinstance(pos_edges, list):
+        pos_edges = torch.as_tensor(pos_edges)
+    dev = a_embeddings.device
+    pos_edges = torch.as_tensor(pos_edges).to(dev)
+    neg_items = torch.as_tensor(neg_items).to(dev)
+    return ops.bpr_gather_dot(a_embeddings, b_embeddings, pos_edges[:, 0], pos_edges[:, 1],
+                              neg_items.reshape(pos_edges.shape[0], -1), mode=ops.LOSS_INFO_BPR)
+
+
+def sgrec_loss(result, batch, reg_weight=0.0):
+    """The SGrec model loss (model/Main_Model.py:902-928):
+    -mean(log(sigmoid(pos - neg))) + reg_weight * (mean(ori_u^2) + mean(ori_i^2)), one negative
+    per sample.  (The reference also builds a 20-random-item cross-entropy term that it never
+    adds to the result; that term only consumes random numbers and is not reproduced.)"""
+    dev = result["user_embeddings"].device
+    empty = torch.tensor([], dtype=torch.long)
+    users = batch.get("user_ids", empty).to(dev)
+    pos = batch.get("item_ids", empty).to(dev)
+    neg = batch.get("neg_items", empty).to(dev).reshape(-1, 1)
+    loss = ops.bpr_gather_dot(result["user_embeddings"], result["item_embeddings"], users, pos, neg,
+                              mode=ops.LOSS_LOG_SIGMOID)
+    reg_loss = torch.mean(result["ori_u_emb"] ** 2) + torch.mean(result["ori_i_emb"] ** 2)
+    return loss + reg_weight * reg_loss

@@ -242,7 +242,7 @@ def proj(x_items, weight, bias, n_users):
 # --------------------------------------------------------------------------
 class _Bpr(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, U, I, users, pos, neg, mask, neg_rank, pos_ptr, pos_items, n_items):
+    def forward(ctx, U, I, users, pos, neg, mask, neg_rank, pos_ptr, pos_items, n_items, mode=0):
         _need_cuda(U, I, users, pos, neg, mask, neg_rank, pos_ptr, pos_items)
         U, I = _f32c(U), _f32c(I)
         users = users.to(torch.int64).contiguous()
@@ -263,12 +263,13 @@ class _Bpr(torch.autograd.Function):
         ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=U.device)
         x = torch.empty((max(B, 1), max(R, 1)), dtype=torch.float32, device=U.device)
         out = torch.empty(2, dtype=torch.float32, device=U.device)
-        _ffi.call("rk_bpr_fwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
+        _ffi.call("rk_rank_loss_fwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
                   c_int64(B), c_int32(R), ptr(mask), ptr(neg_rank), ptr(pos_ptr), ptr(pos_items),
-                  c_int32(int(n_items)), ptr(x), ptr(out), ptr(ws), c_size_t(ws.numel() * 4),
-                  stream_ptr(U.device))
+                  c_int32(int(n_items)), c_int32(int(mode)), ptr(x), ptr(out), ptr(ws),
+                  c_size_t(ws.numel() * 4), stream_ptr(U.device))
         ctx.save_for_backward(U, I, users, pos, neg, mask, x, out)
         ctx.dims = (B, R, D)
+        ctx.mode = int(mode)
         ctx.mark_non_differentiable(neg)
         return out[0], neg
 
@@ -279,15 +280,19 @@ class _Bpr(torch.autograd.Function):
         g = _f32c(g).reshape(1)
         dU = torch.zeros_like(U)
         dI = torch.zeros_like(I)
-        _ffi.call("rk_bpr_bwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
-                  c_int64(B), c_int32(R), ptr(mask), ptr(x), ptr(out), ptr(g), ptr(dU), ptr(dI),
-                  stream_ptr(U.device))
-        return dU, dI, None, None, None, None, None, None, None, None
+        _ffi.call("rk_rank_loss_bwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
+                  c_int64(B), c_int32(R), ptr(mask), ptr(x), ptr(out), ptr(g), c_int32(ctx.mode),
+                  ptr(dU), ptr(dI), stream_ptr(U.device))
+        return dU, dI, None, None, None, None, None, None, None, None, None
 
 
-def bpr_gather_dot(U, I, users, pos, neg, mask=None):
-    """mean(-logsigmoid(<U[u],I[i]> - <U[u],I[n]>)) over B x R (train/graph_trainer.py:255-270)."""
-    loss, _ = _Bpr.apply(U, I, users, pos, neg, mask, None, None, None, I.shape[0])
+LOSS_BPR, LOSS_LOG_SIGMOID, LOSS_INFO_BPR = 0, 1, 2   # RK_LOSS_* of the header
+
+
+def bpr_gather_dot(U, I, users, pos, neg, mask=None, mode=LOSS_BPR):
+    """mean(-logsigmoid(<U[u],I[i]> - <U[u],I[n]>)) over B x R (train/graph_trainer.py:255-270);
+    `mode` selects the other per-pair terms of evalue/loss.py (see the header)."""
+    loss, _ = _Bpr.apply(U, I, users, pos, neg, mask, None, None, None, I.shape[0], mode)
     return loss
 
 

@@ -131,3 +131,55 @@ def test_forward_is_deterministic():
     neg = torch.randint(0, I, (B, 2), generator=g).to(DEV)
     vals = {float(ops.bpr_gather_dot(ue, ie, users, pos, neg)) for _ in range(5)}
     assert len(vals) == 1
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_loss_variants_vs_reference_and_oracle(golden, name):
+    """mmgcn_loss / compute_info_bpr_loss / the SGrec loss on the gather-dot kernels: values
+    against the reference's captured numbers, gradients against autograd through the oracle."""
+    z = golden("loss_cases.npz")
+    ue_c, ie_c = torch.from_numpy(z[f"{name}/user_emb"]), torch.from_numpy(z[f"{name}/item_emb"])
+    users, pos, neg = (torch.from_numpy(z[f"{name}/{k}"]) for k in ("users", "pos", "neg"))
+    edges = torch.stack([users, pos], 1)
+
+    # softmax cross-entropy over [pos, negatives]
+    ue, ie = ue_c.clone().to(DEV).requires_grad_(True), ie_c.clone().to(DEV).requires_grad_(True)
+    loss = rloss.compute_info_bpr_loss(ue, ie, edges, neg)
+    loss.backward()
+    ref = float(z[f"{name}/info_bpr_loss"])
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+    uo, io = ue_c.clone().requires_grad_(True), ie_c.clone().requires_grad_(True)
+    loss_oracle.compute_info_bpr_loss(uo, io, edges, neg).backward()
+    assert relerr(ue.grad.cpu().numpy(), uo.grad.numpy()) <= 1e-5
+    assert relerr(ie.grad.cpu().numpy(), io.grad.numpy()) <= 1e-5
+
+    if neg.shape[1] != 1:
+        return
+    batch = {"user_ids": users, "item_ids": pos, "neg_items": neg}
+    # mmgcn_loss
+    ue, ie = ue_c.clone().to(DEV).requires_grad_(True), ie_c.clone().to(DEV).requires_grad_(True)
+    outputs = {"user_embeddings": ue, "item_embeddings": ie, "id_embeddings": torch.cat([ue, ie]).detach(),
+               "pres": ue.detach()}
+    loss = rloss.mmgcn_loss(outputs, batch)
+    loss.backward()
+    ref = float(z[f"{name}/mmgcn_loss"])
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+    uo, io = ue_c.clone().requires_grad_(True), ie_c.clone().requires_grad_(True)
+    oo = {"user_embeddings": uo, "item_embeddings": io, "id_embeddings": torch.cat([uo, io]).detach(), "pres": uo.detach()}
+    loss_oracle.mmgcn_loss(oo, batch).backward()
+    assert relerr(ue.grad.cpu().numpy(), uo.grad.numpy()) <= 1e-5
+    assert relerr(ie.grad.cpu().numpy(), io.grad.numpy()) <= 1e-5
+    # SGrec loss with its weight-decay term
+    ue, ie = ue_c.clone().to(DEV).requires_grad_(True), ie_c.clone().to(DEV).requires_grad_(True)
+    u0, i0 = (ue_c * 0.5).to(DEV).requires_grad_(True), (ie_c * 0.5).to(DEV).requires_grad_(True)
+    res = {"user_embeddings": ue, "item_embeddings": ie, "ori_u_emb": u0, "ori_i_emb": i0}
+    loss = rloss.sgrec_loss(res, batch, reg_weight=1e-3)
+    loss.backward()
+    uo, io = ue_c.clone().requires_grad_(True), ie_c.clone().requires_grad_(True)
+    u0o, i0o = (ue_c * 0.5).requires_grad_(True), (ie_c * 0.5).requires_grad_(True)
+    lo = loss_oracle.sgrec_loss({"user_embeddings": uo, "item_embeddings": io, "ori_u_emb": u0o, "ori_i_emb": i0o},
+                                batch, 1e-3)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
+    assert relerr(ue.grad.cpu().numpy(), uo.grad.numpy()) <= 1e-5
+    assert relerr(u0.grad.cpu().numpy(), u0o.grad.numpy()) <= 1e-5

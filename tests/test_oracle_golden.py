@@ -179,3 +179,17 @@ def test_config_presets_fixture():
         d = json.load(f)
     assert d["baby"]["data"]["batch_size"] == 2048 and d["baby"]["data"]["num_users"] == 19445
     assert d["elec"]["data"]["batch_size"] == 256 and d["baby"]["evaluation"]["k_values"] == [5, 10, 20]
+
+
+def test_loss_variant_oracles_match_reference(golden):
+    """mmgcn_loss and compute_info_bpr_loss restatements against values captured from evalue.loss."""
+    z = golden("loss_cases.npz")
+    for name in ("b64r1", "b200r4", "b33r3d128"):
+        ue, ie = torch.from_numpy(z[f"{name}/user_emb"]), torch.from_numpy(z[f"{name}/item_emb"])
+        users, pos, neg = (torch.from_numpy(z[f"{name}/{k}"]) for k in ("users", "pos", "neg"))
+        got = float(loss_oracle.compute_info_bpr_loss(ue, ie, torch.stack([users, pos], 1), neg))
+        assert abs(got - float(z[f"{name}/info_bpr_loss"])) <= 1e-6 * abs(float(z[f"{name}/info_bpr_loss"]))
+        if f"{name}/mmgcn_loss" in z:
+            outputs = {"user_embeddings": ue, "item_embeddings": ie, "id_embeddings": torch.cat([ue, ie]), "pres": ue}
+            got = float(loss_oracle.mmgcn_loss(outputs, {"user_ids": users, "item_ids": pos, "neg_items": neg}))
+            assert abs(got - float(z[f"{name}/mmgcn_loss"])) <= 1e-6 * abs(float(z[f"{name}/mmgcn_loss"]))
