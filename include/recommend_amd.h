@@ -278,6 +278,16 @@ int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users,
                       int32_t P, int32_t Kin, int32_t K, float *out_scores,
                       int32_t *out_ids, void *stream);
 
+/* ---- M: top-K of an existing score matrix (device) ------------------------ */
+/* Replaces torch.topk(scores, k, dim=1, largest=True, sorted=True) of
+ * evaluate_all_at_k, evalue/metric.py:114, for callers that hand over the dense
+ * scores[n_rows, n_items] (row stride ld floats).  Ranking: score descending, ties by
+ * lower column id.  out_scores/out_ids: n_rows x K.  1 <= K <= min(n_items, 32). */
+size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K);
+int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items,
+                     int64_t ld, int32_t K, float *out_scores, int32_t *out_ids,
+                     void *ws, size_t ws_bytes, void *stream);
+
 /* ---- M: ranking metrics (device) ---------------------------------------- */
 /* Replaces evaluate_all_at_k, evalue/metric.py:106-164, for every k in k_list
  * at once from one sorted top-Kmax id list per user and the CSR of the target

@@ -341,6 +341,34 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   }
 }
 
+// Top-K of the rows of a score matrix that already exists (evaluate_all_at_k called with
+// precomputed scores).  32 lanes per row, lane j scans columns j, j+32, ... (coalesced 128-B
+// reads) into its own sorted list; the 32 lists of a row are merged by topk_merge_kernel.
+constexpr int ROWS_LANES = 32;
+
+template <int KPAD>
+__global__ __launch_bounds__(256) void rows_topk_kernel(const float *__restrict__ scores, int32_t n_rows,
+                                                        int32_t n_items, int64_t ld,
+                                                        float *__restrict__ part_s,
+                                                        int32_t *__restrict__ part_id) {
+  const int sub = threadIdx.x % ROWS_LANES;
+  const int32_t row = blockIdx.x * (256 / ROWS_LANES) + threadIdx.x / ROWS_LANES;
+  if (row >= n_rows) return;
+  LaneList<KPAD> list;
+  list.init();
+  const float *src = scores + (int64_t)row * ld;
+  for (int32_t i = sub; i < n_items; i += ROWS_LANES) {
+    const float v = src[i];
+    if (v > list.s[KPAD - 1]) list.insert(v, i);   // ascending ids + strict '>' keep lower ids first
+  }
+  const int64_t base = ((int64_t)row * ROWS_LANES + sub) * KPAD;
+#pragma unroll
+  for (int j = 0; j < KPAD; ++j) {
+    part_s[base + j] = list.s[j];
+    part_id[base + j] = list.id[j];
+  }
+}
+
 // One wavefront per user ranks all n = P*Kin candidates by counting how many
 // beat each one; candidates with rank < K are written to their final slot.
 constexpr int MERGE_MAX = 1024;
@@ -543,6 +571,39 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
   }
   if (rc != RK_OK) return rc;
   return rk_topk_merge_f32(ps, pi, n_users, nsplit, kp, K, out_scores, out_ids, stream);
+}
+
+size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K) {
+  if (n_rows <= 0 || K <= 0 || K > 32) return 0;
+  return (size_t)n_rows * ROWS_LANES * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
+}
+
+int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items, int64_t ld, int32_t K,
+                     float *out_scores, int32_t *out_ids, void *ws, size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(n_rows >= 0 && n_items > 0 && ld >= n_items, "bad score matrix shape");
+  // evalue/metric.py:9-10
+  RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
+  if (K > 32) return rk::fail(RK_ERR_UNSUPPORTED, "rk_rows_topk_f32: K=%d above the built maximum 32", K);
+  if (n_rows == 0) return RK_OK;
+  RK_CHECK_ARG(scores && out_scores && out_ids && ws, "null pointer");
+  RK_CHECK_ARG(ws_bytes >= rk_rows_topk_ws_bytes(n_rows, K), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int kp = kpad_for(K);
+  float *ps = (float *)ws;
+  int32_t *pi = (int32_t *)(ps + (size_t)n_rows * ROWS_LANES * kp);
+  const int grid = (int)rk::ceil_div(n_rows, 256 / ROWS_LANES);
+  switch (kp) {
+    case 4: rows_topk_kernel<4><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 8: rows_topk_kernel<8><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 12: rows_topk_kernel<12><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 16: rows_topk_kernel<16><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 20: rows_topk_kernel<20><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 24: rows_topk_kernel<24><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    case 28: rows_topk_kernel<28><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+    default: rows_topk_kernel<32><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
+  }
+  RK_CHECK_LAUNCH("rows_topk_kernel");
+  return rk_topk_merge_f32(ps, pi, n_rows, ROWS_LANES, kp, K, out_scores, out_ids, stream);
 }
 
 size_t rk_rank_metrics_ws_bytes(int32_t n_users, int32_t nk) {

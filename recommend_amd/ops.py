@@ -409,6 +409,23 @@ def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0):
     return out_s, out_i
 
 
+def rows_topk(scores, K):
+    """torch.topk(scores, K, dim=1, largest=True, sorted=True) with ties broken by the lower
+    column id.  Returns (values [B,K] fp32, ids [B,K] int32)."""
+    _need_cuda(scores)
+    scores = _f32c(scores.detach())
+    n_rows, n_items = scores.shape
+    lib = _ffi.load()
+    ws_bytes = lib.rk_rows_topk_ws_bytes(n_rows, K)
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=scores.device)
+    out_s = torch.empty((n_rows, K), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((n_rows, K), dtype=torch.int32, device=scores.device)
+    _ffi.call("rk_rows_topk_f32", ptr(scores), c_int32(n_rows), c_int32(n_items), c_int64(scores.stride(0)),
+              c_int32(K), ptr(out_s), ptr(out_i), ptr(ws), c_size_t(ws.numel() * 4),
+              stream_ptr(scores.device))
+    return out_s, out_i
+
+
 def topk_merge(scores, ids, K):
     """Merge candidate lists [U, P, Kin] into the best K per user by (score desc, id asc)."""
     _need_cuda(scores, ids)

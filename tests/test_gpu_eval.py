@@ -1,5 +1,9 @@
 """GPU parity: fused score + mask + top-K, list merge and ranking metrics against
 the golden vectors of the reference's Verifier and the exact oracle."""
+import json
+import os
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -197,3 +201,42 @@ def test_baby_shape_end_to_end_vs_oracle():
     for k in (5, 10, 20):
         for m in METRICS:
             assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)
+
+
+def test_dense_metric_functions_vs_reference_cases(golden):
+    """evaluate_all_at_k and the single-metric functions on precomputed dense scores
+    (recommend_amd.metric) against the values captured from evalue/metric.py."""
+    from recommend_amd import metric
+    z = golden("metric_cases.npz")
+    err = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "metric_errors.json")))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        s, t = dev(z[f"{name}/scores"]), dev(z[f"{name}/targets"])
+        for k in [int(k) for k in z[f"{name}/ks"] if k <= 32]:
+            got = metric.evaluate_all_at_k(s, t, k)
+            assert list(got.keys()) == ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
+            assert all(v.dim() == 0 for v in got.values())
+            np.testing.assert_allclose([float(v) for v in got.values()], z[f"{name}/all@{k}"], rtol=1e-5, atol=1e-7)
+            if name == "rand_64x500":   # continuous scores: no ties, the reference's ids are the only order
+                assert np.array_equal(ops.rows_topk(s, k)[1].cpu().numpy(), z[f"{name}/topk@{k}"])
+        k = int(z[f"{name}/ks"][0])
+        assert abs(float(metric.ndcg_at_k(s, t, k)) - float(z[f"{name}/all@{k}"][3])) <= 1e-5
+    s, t = torch.rand(4, 9, device=DEV), torch.zeros(4, 9, device=DEV)
+    with pytest.raises(ValueError, match=re.escape(err["k0"])):
+        metric.evaluate_all_at_k(s, t, 0)
+    with pytest.raises(ValueError, match=re.escape(err["k_gt"])):
+        metric.evaluate_all_at_k(s, t, 10)
+    with pytest.raises(ValueError, match=re.escape(err["shape"])):
+        metric.evaluate_all_at_k(s, t[:, :8], 3)
+    with pytest.raises(ValueError, match=re.escape(err["dim"])):
+        metric.evaluate_all_at_k(s[0], t[0], 3)
+
+
+def test_rows_topk_ties_and_oracle():
+    """Dense top-K: ids exact against a stable sort by (score desc, id asc), with heavy ties."""
+    rng = np.random.default_rng(11)
+    for (B, I, K) in ((7, 40, 5), (130, 1000, 20), (33, 77, 32), (5, 3, 3)):
+        s = rng.integers(0, 6, size=(B, I)).astype(np.float32)      # many equal scores
+        vals, ids = ops.rows_topk(dev(s), K)
+        order = np.lexsort((np.broadcast_to(np.arange(I), (B, I)), -s), axis=1)[:, :K]
+        assert np.array_equal(ids.cpu().numpy(), order.astype(np.int32))
+        assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(s, order, 1))
