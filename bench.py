@@ -74,26 +74,57 @@ def event_ms(fn, reps):
     return start.elapsed_time(stop) / reps
 
 
-def cpu_baseline_eval(ue, ie, train, val, n_sample_users, seed=0):
+def cpu_baseline_eval(ue, ie, train, val, chunk_users, budget_s=8.0):
     """Reference-style evaluation (oracle/eval_oracle.verify: matmul -> index_put(-1e10) ->
-    topk x3 -> metrics incl. the per-row python loop) on a chunk of users, all host cores."""
+    topk x3 -> metrics incl. the per-row python loop) on chunks of users until the time budget
+    is spent, all host cores.  Metrics are per-user means, so chunking is exact."""
     from oracle import eval_oracle
     tu, ti = train
     vu, vi = val
     U, I = ue.shape[0], ie.shape[0]
-    n = min(n_sample_users, U)
-    sel = np.arange(n)          # first n users: metrics are per-user means, any chunk is exact
-    tm = tu < n
-    vm = vu < n
-    target = torch.zeros((n, I))
-    target[torch.from_numpy(vu[vm]), torch.from_numpy(vi[vm])] = 1
-    row_id, col_id = tu[tm].tolist(), ti[tm].tolist()
-    uc, ic = torch.from_numpy(ue[sel]), torch.from_numpy(ie)
-    torch.set_num_threads(os.cpu_count() if os.cpu_count() <= 64 else 16)
+    ic = torch.from_numpy(ie)
+    torch.set_num_threads(min(os.cpu_count(), 16))
+    done, total = 0, 0.0
+    while done < U and total < budget_s:
+        lo, hi = done, min(done + chunk_users, U)
+        tm = (tu >= lo) & (tu < hi)
+        vm = (vu >= lo) & (vu < hi)
+        target = torch.zeros((hi - lo, I))
+        target[torch.from_numpy(vu[vm] - lo), torch.from_numpy(vi[vm])] = 1
+        row_id, col_id = (tu[tm] - lo).tolist(), ti[tm].tolist()
+        uc = torch.from_numpy(ue[lo:hi])
+        t0 = time.perf_counter()
+        eval_oracle.verify(uc, ic, target, row_id, col_id, K_LIST, METRICS)
+        total += time.perf_counter() - t0
+        done = hi
+    return done / total, total, torch.get_num_threads(), done
+
+
+def cpu_baseline_train(model, feats, coo, batch, U, I, reps_spmm=5):
+    """The oracle's CPU training step (torch CPU ops as the reference applies them, torch.sparse.mm
+    standing in for DGL): one SpMM hop timed alone, and one forward + BPR loss + backward."""
+    from oracle import graph_oracle, loss_oracle, mmfcn_oracle
+    src, dst, w = coo
+    N = U + I
+    wn, _ = graph_oracle.normalize(src, dst, w, N)
+    A = mmfcn_oracle.adjacency(src, dst, wn, N)
+    h = torch.randn(N, model.config.model.emb_dim)
+    torch.sparse.mm(A, h)
     t0 = time.perf_counter()
-    eval_oracle.verify(uc, ic, target, row_id, col_id, K_LIST, METRICS)
-    dt = time.perf_counter() - t0
-    return n / dt, dt, torch.get_num_threads(), n
+    for _ in range(reps_spmm):
+        torch.sparse.mm(A, h)
+    ms_hop = 1e3 * (time.perf_counter() - t0) / reps_spmm
+    p = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    padded = [torch.cat([torch.zeros(U, f.shape[1]), f]) for f in feats.values()]
+    embs = model.embs.detach().cpu().clone().requires_grad_(True)
+    alphas = model.alphas.detach().cpu().clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"], embs, model.ks, alphas,
+                                  model.config.model.layer_num, U)
+    loss = loss_oracle.trainer_loss({"user_embeddings": ue, "item_embeddings": ie},
+                                    {k: batch[k].cpu() for k in ("user_ids", "item_ids", "neg_items")})
+    loss.backward()
+    return ms_hop, 1e3 * (time.perf_counter() - t0)
 
 
 def main():
@@ -207,6 +238,7 @@ def main():
 
     # ---------------------------------------------------------------- one training epoch
     epoch = None
+    last_batch = {}
     if args.epoch_steps != 0 and world == 1:
         p_ptr, p_items = build_user_csr(data.users, data.items, U)
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
@@ -222,6 +254,7 @@ def main():
             batch["pos_ptr"], batch["pos_items"] = dp, di
             opt.zero_grad(set_to_none=True)
             loss = gather_dot_bpr_loss(model(batch), batch)
+            last_batch.update(batch)     # (the loss call fills in the negatives it resolved)
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
             opt.step()
@@ -250,7 +283,15 @@ def main():
         v, dt, cores, n = cpu_baseline_eval(ue.cpu().numpy(), ie.cpu().numpy(), (tu, ti), (vu, vi), args.cpu_users)
         cpu = {"value": round(v, 1), "unit": "users/s", "cores": cores, "kind": "port",
                "sample": f"reference-style verify (matmul, index_put -1e10, topk x3, metrics) on the first {n} "
-                         f"users x {I} items, {dt:.2f} s"}
+                         f"users x {I} items in chunks of {args.cpu_users}, {dt:.2f} s"}
+        if epoch is not None:
+            from oracle import graph_oracle
+            coo = graph_oracle.build_coo_vectorized(tu, ti, tr, U, I, True)
+            ms_hop, ms_step = cpu_baseline_train(model, feats, coo, last_batch, U, I)
+            cpu["spmm_hop_ms"] = round(ms_hop, 3)
+            cpu["train_step_ms"] = round(ms_step, 1)
+            cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \
+                                  "oracle's MMFCN at the same shape, no warm-up step"
 
     if rank == 0:
         line = {
