@@ -12,10 +12,19 @@
 // sums of dW/db/d(alpha) are reduced in workgroup order by a second launch (no
 // float atomics, bitwise reproducible).
 //
+// Both kernels are persistent and every wavefront works alone on tiles of 32 rows
+// (no workgroup barrier in the loop): it stages its rows by LDS-DMA into a private,
+// XOR-swizzled LDS tile while the previous tile is still being multiplied, keeps
+// the weight fragments in registers for the whole launch, and reads / writes
+// everything else straight from the accumulator layout, whose 32 lanes per row
+// segment make 128-byte coalesced accesses.
+//
 // MFMA operand maps (32x32x2): lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]; the result register r of lane l is C[(r&3) + 8*(r>>2) +
 // 4*(l>>5)][l&31].  K is walked as (k, k+32) pairs so that a lane's 32 operand
-// values are contiguous in its LDS row.
+// values are contiguous in its row.
+#include <type_traits>
+
 #include "common.h"
 #include "slab_reduce.h"
 
@@ -25,29 +34,78 @@ using rk::kWave;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int DD = 64;        // layer width (in = out)
-constexpr int LDW = DD + 4;   // padded LDS row: conflict-free b128 row reads
+constexpr int WT = 32;        // rows per wavefront tile
+constexpr int LDZ = DD + 4;   // padded row of the dZ tile: conflict-free b128 row reads
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// counter-based dropout decision, identical in forward and backward
-__device__ __forceinline__ bool keep_elem(uint32_t seed_lo, uint32_t seed_hi, uint64_t idx,
-                                          uint32_t thresh24) {
-  uint32_t x = (uint32_t)idx * 0x9E3779B1u ^ seed_lo;
-  x ^= (uint32_t)(idx >> 32) * 0x85EBCA77u;
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x += seed_hi;
-  x *= 0xC2B2AE35u;
-  x ^= x >> 16;
-  return (x >> 8) >= thresh24;
+// Counter-based dropout, identical in forward and backward.  One hash covers the 2 x 2 block
+// (rows 2i, 2i+1) x (columns 2j, 2j+1): 64 bits = four 16-bit fields, field (row&1, col&1).
+// An element is kept when its field is >= thresh16 = round(p * 65536).
+struct DropQuad {
+  uint32_t lo, hi;   // fields of the even row, of the odd row
+};
+__device__ __forceinline__ DropQuad drop_quad(uint32_t seed_lo, uint32_t seed_hi, uint32_t row_pair,
+                                              uint32_t col_term) {
+  uint32_t x = row_pair * 0x9E3779B1u + col_term;   // col_term = (col >> 1) * 0x85EBCA77 ^ seed_lo
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  x *= 0x297A2D39u;
+  x ^= x >> 15;
+  uint32_t y = (x ^ seed_hi) * 0x85EBCA6Bu;
+  y ^= y >> 13;
+  return DropQuad{x, y};
+}
+__device__ __forceinline__ bool kept(uint32_t word, int col_odd, uint32_t thresh16) {
+  return ((word >> (16 * col_odd)) & 0xFFFFu) >= thresh16;
 }
 
-// 32 operand values of one lane: row `row` of an LDS tile, columns 32*half .. 32*half+31
-__device__ __forceinline__ void load_frag(const float *tile, int row, int half, float (&f)[32]) {
+// --------------------------------------------------------------- tile staging
+// One wave-instruction of LDS-DMA writes 64 x 16 B = 1 KiB of LDS linearly from per-lane global
+// addresses: piece p of a tile holds rows 4p..4p+3, and slot s of row r holds the 16-byte chunk
+// s ^ (r & 15) of that row, so that both the row-per-lane b128 reads and the column-per-lane b32
+// reads below are (nearly) conflict free without padding.
+__device__ __forceinline__ uint32_t dma_lane_off(int lane) {
+  const int l_row = lane >> 4, l_slot = lane & 15;
+  return (uint32_t)(l_row * 256 + ((l_slot ^ l_row) * 16));
+}
+
+__device__ __forceinline__ void stage_rows(const float *__restrict__ M, int64_t row0, int64_t n_rows,
+                                           float *dst, uint32_t lane_off) {
+  if (row0 + WT <= n_rows) {
+    const char *base = reinterpret_cast<const char *>(M + row0 * DD);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t off = (lane_off ^ (uint32_t)(((4 * p) & 15) * 16)) + (uint32_t)(p * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
+                                       (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+    }
+    return;
+  }
+  // last, partial tile: rows past the end re-read the last row (their results are never stored,
+  // and they enter the weight gradient with a zero factor)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const uint32_t off = lane_off ^ (uint32_t)(((4 * p) & 15) * 16);
+    int64_t row = row0 + 4 * p + (int64_t)(off >> 8);
+    row = row < n_rows ? row : n_rows - 1;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(M + row * DD) + (off & 255)),
+        (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+  }
+}
+
+// row `col` of a staged tile, columns 32*half .. 32*half+31: chunk 8*half+q sits in slot
+// (8*half+q) ^ (col & 15); q < 8 only touches bits the other terms leave alone
+__device__ __forceinline__ uint32_t frag_lane_off(int col, int half) {
+  return (uint32_t)(col * 256 + (((8 * half) ^ (col & 15)) * 16));
+}
+__device__ __forceinline__ void load_row_frag(const float *tile, uint32_t frag_off, float (&f)[32]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDW + 32 * half + 4 * q]);
+    const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tile) +
+                                                       (frag_off ^ (uint32_t)(q * 16)));
     f[4 * q + 0] = v.x;
     f[4 * q + 1] = v.y;
     f[4 * q + 2] = v.z;
@@ -55,223 +113,357 @@ __device__ __forceinline__ void load_frag(const float *tile, int row, int half, 
   }
 }
 
-// copy a rows x 64 fp32 block (global row-major) into a padded LDS tile; rows past n_valid are zero
-template <int ROWS>
-__device__ __forceinline__ void stage_tile(const float *__restrict__ g, int64_t row0, int64_t n_rows,
-                                           float *tile, int tid) {
-  constexpr int PER = ROWS * 16 / 256;
+// 32 weight values of one lane, from global memory (once per launch): row `row` of W,
+// columns 32*half .. 32*half+31
+__device__ __forceinline__ void load_w_row(const float *__restrict__ W, int row, int half, float (&f)[32]) {
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int e = tid + 256 * j, r = e >> 4, c = (e & 15) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row0 + r < n_rows) v = *reinterpret_cast<const float4 *>(g + (row0 + r) * DD + c);
-    *reinterpret_cast<float4 *>(&tile[r * LDW + c]) = v;
+  for (int q = 0; q < 8; ++q) {
+    const float4 v = *reinterpret_cast<const float4 *>(W + row * DD + 32 * half + 4 * q);
+    f[4 * q + 0] = v.x;
+    f[4 * q + 1] = v.y;
+    f[4 * q + 2] = v.z;
+    f[4 * q + 3] = v.w;
   }
 }
 
 // ------------------------------------------------------------------ forward
-constexpr int FBM = 128;  // rows per workgroup tile (4 wavefronts x 32)
-
-template <bool DUAL>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(
+template <bool DUAL, bool HAS_R>
+__global__ __launch_bounds__(256, DUAL ? 1 : 2) void dense_fwd_kernel(
     const float *__restrict__ X1, const float *__restrict__ W1, const float *__restrict__ X2,
     const float *__restrict__ W2, const float *__restrict__ b1, const float *__restrict__ b2,
     const float *__restrict__ alpha, float p_drop, uint32_t seed_lo, uint32_t seed_hi,
     const float *__restrict__ R, int64_t n_rows, float *__restrict__ Y) {
-  __shared__ __attribute__((aligned(16))) float Ws[DD * LDW];
-  __shared__ __attribute__((aligned(16))) float Xs[FBM * LDW];
+  // separate arrays: a DMA into one is known not to alias reads of the other
+  __shared__ __attribute__((aligned(1024))) float xa[4][WT * DD];
+  __shared__ __attribute__((aligned(1024))) float xb[DUAL ? 4 : 1][DUAL ? WT * DD : 4];
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * FBM;
+  const int64_t n_tiles = (n_rows + WT - 1) / WT;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= n_tiles) return;   // wave-uniform; there is no workgroup barrier below
 
-  floatx16 acc[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  uint32_t lane_off = dma_lane_off(lane);
+  uint32_t frag_off = frag_lane_off(col, half);
+  stage_rows(X1, tile * WT, n_rows, xa[wave], lane_off);
+  if constexpr (DUAL) stage_rows(X2, tile * WT, n_rows, xb[DUAL ? wave : 0], lane_off);
 
-#pragma unroll
-  for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
-    if (pass) __syncthreads();
-    stage_tile<DD>(pass ? W2 : W1, 0, DD, Ws, tid);
-    stage_tile<FBM>(pass ? X2 : X1, row0, n_rows, Xs, tid);
-    __syncthreads();
-    float a[32], b[32];
-    load_frag(Xs, wave * 32 + col, half, a);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      load_frag(Ws, 32 * t + col, half, b);
-#pragma unroll
-      for (int m = 0; m < 32; ++m)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc[t], 0, 0, 0);
-    }
-  }
-
-  const float al = alpha ? alpha[0] : 1.0f;
-  const bool act = alpha != nullptr;
-  const bool drop = p_drop > 0.0f;
-  const uint32_t thresh = (uint32_t)(p_drop * 16777216.0f);
-  const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  // B operand: W[n = 32t + col][k = 32*half + m], kept in registers for the whole launch
+  float w1[2][32], w2[DUAL ? 2 : 1][DUAL ? 32 : 1];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int n = 32 * t + col;
-    float bias = b1 ? b1[n] : 0.0f;
-    if (DUAL && b2) bias += b2[n];
+    load_w_row(W1, 32 * t + col, half, w1[t]);
+    if constexpr (DUAL) load_w_row(W2, 32 * t + col, half, w2[DUAL ? t : 0]);
+  }
+  float bias[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = row0 + wave * 32 + crow(r, half);
-      if (row < n_rows) {
-        float z = acc[t][r] + bias;
-        if (act) z = z > 0.0f ? z : al * z;
-        if (drop) z = keep_elem(seed_lo, seed_hi, (uint64_t)row * DD + n, thresh) ? z * scale : 0.0f;
-        if (R) z += R[row * DD + n];
-        Y[row * DD + n] = z;
+  for (int t = 0; t < 2; ++t) {
+    bias[t] = b1 ? b1[32 * t + col] : 0.0f;
+    if (DUAL && b2) bias[t] += b2[32 * t + col];
+  }
+  const float al = alpha ? alpha[0] : 1.0f;   // no activation = slope 1
+  const bool drop = p_drop > 0.0f;
+  const uint32_t thresh = (uint32_t)(p_drop * 65536.0f + 0.5f);
+  const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+  uint32_t col_term[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) col_term[t] = (uint32_t)((32 * t + col) >> 1) * 0x85EBCA77u ^ seed_lo;
+
+  for (; tile < n_tiles; tile += stride) {
+    const int64_t row0 = tile * WT;
+    const int64_t next = tile + stride;
+    asm volatile("" : "+v"(lane_off), "+v"(frag_off));   // keep per-piece addresses out of registers
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // residual rows in accumulator layout, issued before the MFMAs that hide their latency
+    const bool full = row0 + WT <= n_rows;   // wave-uniform: only the last tile can be partial
+    float res[HAS_R ? 2 : 1][HAS_R ? 16 : 1];
+    if constexpr (HAS_R) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + crow(r, half);
+          res[HAS_R ? t : 0][HAS_R ? r : 0] = (full || row < n_rows) ? R[row * DD + 32 * t + col] : 0.0f;
+        }
+    }
+
+    float a[32];
+    load_row_frag(xa[wave], frag_off, a);
+    // the fragment is in registers: the tile buffer is free for the next tile's DMA, which then
+    // has this tile's MFMAs and epilogue to land
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    if (next < n_tiles) stage_rows(X1, next * WT, n_rows, xa[wave], lane_off);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w1[t][m], acc[t], 0, 0, 0);
+    if constexpr (DUAL) {
+      load_row_frag(xb[DUAL ? wave : 0], frag_off, a);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (next < n_tiles) stage_rows(X2, next * WT, n_rows, xb[DUAL ? wave : 0], lane_off);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 32; ++m)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w2[DUAL ? t : 0][DUAL ? m : 0], acc[t], 0, 0, 0);
+    }
+
+    // epilogue in accumulator layout: lane = column 32t + col, registers = rows.  Compiled four
+    // times (dropout on/off, full/partial tile) and selected by two wave-uniform branches per
+    // tile, so that the per-element code is straight-line; no activation is alpha = 1.
+    auto epilogue = [&](auto drop_tag, auto full_tag) {
+      constexpr bool kDrop = decltype(drop_tag)::value, kFull = decltype(full_tag)::value;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n = 32 * t + col;
+        float *yp = Y + row0 * DD + n;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          // rows crow(r) (even) and crow(r) + 1 share one dropout hash
+          DropQuad dq{0u, 0u};
+          if constexpr (kDrop)
+            dq = drop_quad(seed_lo, seed_hi, (uint32_t)((row0 + crow(r, half)) >> 1), col_term[t]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float z = acc[t][r + e] + bias[t];
+            z = z > 0.0f ? z : al * z;
+            if constexpr (kDrop) z = kept(e ? dq.hi : dq.lo, n & 1, thresh) ? z * scale : 0.0f;
+            if constexpr (HAS_R) z += res[HAS_R ? t : 0][HAS_R ? r + e : 0];
+            if (kFull || row0 + crow(r + e, half) < n_rows) yp[crow(r + e, half) * DD] = z;
+          }
+        }
       }
+    };
+    if (drop) {
+      if (full) epilogue(std::true_type{}, std::true_type{});
+      else epilogue(std::true_type{}, std::false_type{});
+    } else {
+      if (full) epilogue(std::false_type{}, std::true_type{});
+      else epilogue(std::false_type{}, std::false_type{});
     }
   }
 }
 
 // ----------------------------------------------------------------- backward
-constexpr int BBM = 64;                       // rows per tile
 constexpr int PART = DD * DD + DD + 8;        // per-workgroup partial: dW, db, d(alpha) (+pad)
 
-// ACT: Y = dropout(prelu(X W^T + b)); otherwise Y = X W^T + b (dZ = G).
+// ACT: Y = dropout(prelu(X W^T + b)); otherwise Y = dropout(X W^T + b) (dZ = mask * G).
 template <bool ACT>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(
+__global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ b,
     const float *__restrict__ alpha, float p_drop, uint32_t seed_lo, uint32_t seed_hi,
-    const float *__restrict__ G, int64_t n_rows, int32_t n_tiles, float *__restrict__ dX,
-    float *__restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float Ws[DD * LDW];
-  __shared__ __attribute__((aligned(16))) float Xs[BBM * LDW];
-  __shared__ __attribute__((aligned(16))) float Zs[BBM * LDW];   // dZ tile
-  __shared__ float red[4][DD + 1];
+    const float *__restrict__ G, int64_t n_rows, float *__restrict__ dX, float *__restrict__ part) {
+  __shared__ __attribute__((aligned(1024))) float x0[4][WT * DD];   // X tiles, double buffered:
+  __shared__ __attribute__((aligned(1024))) float x1[4][WT * DD];   // the tile is read again for dW
+  __shared__ __attribute__((aligned(16))) float zt[4][WT * LDZ];    // dZ tile (layout change for dX)
+  __shared__ float red_b[4][DD + 1];
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
-  const int rt = wave & 1, ct = wave >> 1;   // this wavefront's 32x32 sub-tile (row tile, column tile)
+  const int64_t n_tiles = (n_rows + WT - 1) / WT;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
 
-  stage_tile<DD>(W, 0, DD, Ws, tid);
+  uint32_t lane_off = dma_lane_off(lane);
+  uint32_t frag_off = frag_lane_off(col, half);
+  // column-per-lane read of a staged tile: X[crow(r, half)][32*kt + col]
+  uint32_t xcol_off = (uint32_t)(half * 4 * 256 + (((col >> 2) ^ (4 * half)) * 16) + (col & 3) * 4);
+  if (tile < n_tiles) stage_rows(X, tile * WT, n_rows, x0[wave], lane_off);
+
+  // W[n = 32t + col][k = 32*half + m]: B operand of Z = X W^T
+  float wz[ACT ? 2 : 1][ACT ? 32 : 1];
+  // W[n = 32*half + m][k = 32*kt + col]: B operand of dX = dZ W
+  float wx[2][32];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if constexpr (ACT) load_w_row(W, 32 * t + col, half, wz[ACT ? t : 0]);
+#pragma unroll
+    for (int m = 0; m < 32; ++m) wx[t][m] = dX ? W[(32 * half + m) * DD + 32 * t + col] : 0.0f;
+  }
   const float al = ACT ? alpha[0] : 1.0f;
   const bool drop = p_drop > 0.0f;
-  const uint32_t thresh = (uint32_t)(p_drop * 16777216.0f);
+  const uint32_t thresh = (uint32_t)(p_drop * 65536.0f + 0.5f);
   const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
-  const float bias = (ACT && b) ? b[32 * ct + col] : 0.0f;
-
-  floatx16 dw;   // dW[n = 32*rt + row-of-C][k = 32*ct + col], accumulated over all tiles of this workgroup
+  float bias[2];
+  uint32_t col_term[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dw[r] = 0.0f;
-  float db_acc = 0.0f, da_acc = 0.0f;
+  for (int t = 0; t < 2; ++t) {
+    bias[t] = (ACT && b) ? b[32 * t + col] : 0.0f;
+    col_term[t] = (uint32_t)((32 * t + col) >> 1) * 0x85EBCA77u ^ seed_lo;
+  }
 
-  for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = (int64_t)tile * BBM;
-    __syncthreads();   // previous tile's readers are done (also orders the W staging the first time)
-    stage_tile<BBM>(X, row0, n_rows, Xs, tid);
-    if (!ACT) {
-      // dZ = G (times the dropout mask when the layer is linear + dropout)
+  // dW[n = 32t + crow(r)][k = 32kt + col], accumulated over all tiles of this wavefront
+  floatx16 dw[2][2];
 #pragma unroll
-      for (int j = 0; j < BBM * 16 / 256; ++j) {
-        const int e = tid + 256 * j, r = e >> 4, c = (e & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < n_rows) {
-          v = *reinterpret_cast<const float4 *>(G + (row0 + r) * DD + c);
-          if (drop) {
-            const uint64_t idx = (uint64_t)(row0 + r) * DD + c;
-            v.x = keep_elem(seed_lo, seed_hi, idx + 0, thresh) ? v.x * scale : 0.0f;
-            v.y = keep_elem(seed_lo, seed_hi, idx + 1, thresh) ? v.y * scale : 0.0f;
-            v.z = keep_elem(seed_lo, seed_hi, idx + 2, thresh) ? v.z * scale : 0.0f;
-            v.w = keep_elem(seed_lo, seed_hi, idx + 3, thresh) ? v.w * scale : 0.0f;
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw[t][kt][r] = 0.0f;
+  float db_acc[2] = {0.0f, 0.0f}, da_acc = 0.0f;
+
+  // one tile: X in `cur`; the next tile's DMA goes to `nxt`
+  auto do_tile = [&](int64_t tl, const float *cur, float *nxt) {
+    const int64_t row0 = tl * WT;
+    asm volatile("" : "+v"(lane_off), "+v"(frag_off), "+v"(xcol_off));
+    if (tl + stride < n_tiles) stage_rows(X, (tl + stride) * WT, n_rows, nxt, lane_off);
+
+    // upstream gradient in accumulator layout (lane = column, registers = rows)
+    const bool full = row0 + WT <= n_rows;   // wave-uniform: only the last tile can be partial
+    float dz[2][16];
+    if (full) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dz[t][r] = G[(row0 + crow(r, half)) * DD + 32 * t + col];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + crow(r, half);
+          dz[t][r] = row < n_rows ? G[row * DD + 32 * t + col] : 0.0f;
+        }
+    }
+
+    floatx16 z[2];
+    if constexpr (ACT) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[t][r] = 0.0f;
+      float a[32];
+      load_row_frag(cur, frag_off, a);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 32; ++m)
+          z[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], wz[ACT ? t : 0][ACT ? m : 0], z[t], 0, 0, 0);
+    }
+    // dZ = dropout mask * scale * G, through the PReLU derivative at the recomputed Z (compiled
+    // with and without the mask, selected by one wave-uniform branch per tile)
+    auto make_dz = [&](auto drop_tag) {
+      constexpr bool kDrop = decltype(drop_tag)::value;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int n = 32 * t + col;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          DropQuad dq{0u, 0u};
+          if constexpr (kDrop)
+            dq = drop_quad(seed_lo, seed_hi, (uint32_t)((row0 + crow(r, half)) >> 1), col_term[t]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float gs = dz[t][r + e];
+            if constexpr (kDrop) gs = kept(e ? dq.hi : dq.lo, n & 1, thresh) ? gs * scale : 0.0f;
+            if constexpr (ACT) {
+              const float zz = z[t][r + e] + bias[t];
+              const bool pos = zz > 0.0f;
+              da_acc += pos ? 0.0f : zz * gs;       // torch prelu backward: z > 0 ? g : alpha * g
+              gs = pos ? gs : al * gs;
+            }
+            db_acc[t] += gs;
+            dz[t][r + e] = gs;
+            zt[wave][crow(r + e, half) * LDZ + n] = gs;
           }
         }
-        *reinterpret_cast<float4 *>(&Zs[r * LDW + c]) = v;
       }
-    }
-    __syncthreads();
+    };
+    if (drop) make_dz(std::true_type{});
+    else make_dz(std::false_type{});
 
-    if (ACT) {
-      // upstream gradient in accumulator layout, issued before the MFMAs that hide its latency
-      float g[16];
+    // dW[n][k] += sum_row dZ[row][n] X[row][k]: A = dZ as it stands (i = n on the lanes, the
+    // reduction index walks the rows crow(r, half)), B = X read column-per-lane from the tile
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float xc[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + 32 * rt + crow(r, half);
-        g[r] = row < n_rows ? G[row * DD + 32 * ct + col] : 0.0f;
+        const uint32_t off = (xcol_off ^ (uint32_t)((r & 3) * 16)) +
+                             (uint32_t)(((r & 3) + 8 * (r >> 2)) * 256 + 8 * (kt ^ ((r >> 2) & 1)) * 16);
+        xc[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(cur) + off);
       }
-      floatx16 z;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-      float a[32], bw[32];
-      load_frag(Xs, 32 * rt + col, half, a);
-      load_frag(Ws, 32 * ct + col, half, bw);
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int m = 0; m < 32; ++m) z = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bw[m], z, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = 32 * rt + crow(r, half);
-        const int64_t row = row0 + lrow;
-        const float zz = z[r] + bias;
-        float gs = g[r];
-        if (drop)
-          gs = keep_elem(seed_lo, seed_hi, (uint64_t)row * DD + 32 * ct + col, thresh) ? gs * scale : 0.0f;
-        const bool pos = zz > 0.0f;
-        const float dz = pos ? gs : al * gs;     // torch prelu backward: z > 0 ? g : alpha * g
-        da_acc += pos ? 0.0f : zz * gs;
-        db_acc += dz;
-        Zs[lrow * LDW + 32 * ct + col] = dz;
-      }
-      __syncthreads();
-    } else {
-      // db from the staged gradient: column (tid & 63), rows strided by 4 over the tile
-#pragma unroll
-      for (int r = 0; r < BBM / 4; ++r) db_acc += Zs[(4 * r + (tid >> 6)) * LDW + (tid & 63)];
+        for (int r = 0; r < 16; ++r)
+          dw[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[t][r], xc[r], dw[t][kt], 0, 0, 0);
     }
 
     if (dX) {
-      // dX[row][k] = sum_n dZ[row][n] W[n][k]   (A = dZ rows, B = W columns)
-      floatx16 dx;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
+      // dX[row][k] = sum_n dZ[row][n] W[n][k]: A = dZ rows (row-per-lane from the dZ tile)
       float a[32];
-      load_frag(Zs, 32 * rt + col, half, a);
 #pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        const float bv = Ws[(32 * half + m) * LDW + 32 * ct + col];
-        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv, dx, 0, 0, 0);
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(&zt[wave][col * LDZ + 32 * half + 4 * q]);
+        a[4 * q + 0] = v.x;
+        a[4 * q + 1] = v.y;
+        a[4 * q + 2] = v.z;
+        a[4 * q + 3] = v.w;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + 32 * rt + crow(r, half);
-        if (row < n_rows) dX[row * DD + 32 * ct + col] = dx[r];
+      for (int kt = 0; kt < 2; ++kt) {
+        floatx16 dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], wx[kt][m], dx, 0, 0, 0);
+        float *dxp = dX + row0 * DD + 32 * kt + col;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dxp[crow(r, half) * DD] = dx[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (row0 + crow(r, half) < n_rows) dxp[crow(r, half) * DD] = dx[r];
+        }
       }
     }
-    // dW[n][k] += sum_row dZ[row][n] X[row][k]   (A[i=n][kk=row], B[kk=row][j=k]); rows past the end are zero
-#pragma unroll
-    for (int kk = 0; kk < BBM; kk += 2) {
-      const float av = Zs[(kk + half) * LDW + 32 * rt + col];
-      const float bv = Xs[(kk + half) * LDW + 32 * ct + col];
-      dw = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dw, 0, 0, 0);
-    }
+  };
+
+  for (; tile < n_tiles; tile += 2 * stride) {
+    do_tile(tile, x0[wave], x1[wave]);
+    if (tile + stride < n_tiles) do_tile(tile + stride, x1[wave], x0[wave]);
   }
 
-  // per-workgroup partials: dW[64][64], db[64], d(alpha)
-  float *out = part + (int64_t)blockIdx.x * PART;
+  // ---- per-workgroup partials: the four wavefronts' sums are added in wavefront order
+  __syncthreads();                 // every wavefront is done with its tiles: x0 is free
+  float *red = &x0[0][0];          // 64 x 64 floats
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) out[(32 * rt + crow(r, half)) * DD + 32 * ct + col] = dw[r];
-  __syncthreads();
-  if (ACT) {
-    // lanes l and l+32 hold different rows of column 32*ct+col; wavefronts rt = 0,1 share the column
-    db_acc += __shfl_xor(db_acc, 32, kWave);
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) da_acc += __shfl_xor(da_acc, off, kWave);
-    if (half == 0) red[wave][col] = db_acc;
-    if (lane == 0) red[wave][DD] = da_acc;
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = (32 * t + crow(r, half)) * DD + 32 * kt + col;
+            red[idx] = (w == 0 ? 0.0f : red[idx]) + dw[t][kt][r];
+          }
+    }
     __syncthreads();
-    if (tid < DD) out[DD * DD + tid] = red[2 * (tid >> 5)][tid & 31] + red[2 * (tid >> 5) + 1][tid & 31];
-    if (tid == 0) out[DD * DD + DD] = ((red[0][DD] + red[1][DD]) + red[2][DD]) + red[3][DD];
-  } else {
-    red[tid >> 6][tid & 63] = db_acc;
-    __syncthreads();
-    if (tid < DD) out[DD * DD + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-    if (tid == 0) out[DD * DD + DD] = 0.0f;
   }
+  float *out = part + (int64_t)blockIdx.x * PART;
+  for (int i = tid; i < DD * DD; i += 256) out[i] = red[i];
+  // db: lanes l and l+32 hold different rows of the same column; d(alpha): every lane
+#pragma unroll
+  for (int t = 0; t < 2; ++t) db_acc[t] += __shfl_xor(db_acc[t], 32, kWave);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) da_acc += __shfl_xor(da_acc, off, kWave);
+  if (half == 0) {
+    red_b[wave][col] = db_acc[0];
+    red_b[wave][32 + col] = db_acc[1];
+  }
+  if (lane == 0) red_b[wave][DD] = da_acc;
+  __syncthreads();
+  if (tid <= DD)
+    out[DD * DD + tid] = ((red_b[0][tid] + red_b[1][tid]) + red_b[2][tid]) + red_b[3][tid];
 }
 
 // last step of the partial reduction: adds the segment sums and routes them to dW / db / dalpha
@@ -291,9 +483,26 @@ __global__ __launch_bounds__(256) void dense_route_kernel(const float *__restric
     dalpha[0] = s;
 }
 
+inline int cu_count() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
+// persistent grids: forward two workgroups per CU, backward one (its kernel needs the register file)
+inline int fwd_grid(int64_t n_rows) {
+  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), 2 * (int64_t)cu_count());
+}
+constexpr int kBwdMaxGrid = 512;
 inline int bwd_grid(int64_t n_rows) {
-  const int64_t tiles = rk::ceil_div(n_rows, BBM);
-  return (int)std::min<int64_t>(tiles, 768);
+  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4),
+                                std::min<int64_t>(cu_count(), kBwdMaxGrid));
 }
 
 }  // namespace
@@ -315,20 +524,29 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                    rk::aligned16(Y),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)rk::ceil_div(n_rows, FBM);
+  const unsigned grid = (unsigned)fwd_grid(n_rows);
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-  if (X2)
-    dense_fwd_kernel<true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, lo, hi, residual, n_rows, Y);
-  else
-    dense_fwd_kernel<false><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, lo, hi,
-                                                   residual, n_rows, Y);
+  if (X2) {
+    if (residual)
+      dense_fwd_kernel<true, true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, lo, hi, residual, n_rows, Y);
+    else
+      dense_fwd_kernel<true, false><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, lo, hi, nullptr, n_rows, Y);
+  } else {
+    if (residual)
+      dense_fwd_kernel<false, true><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, lo, hi,
+                                                           residual, n_rows, Y);
+    else
+      dense_fwd_kernel<false, false><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, lo, hi,
+                                                            nullptr, n_rows, Y);
+  }
   RK_CHECK_LAUNCH("dense_fwd_kernel");
   return RK_OK;
 }
 
 size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D) {
   if (n_rows <= 0 || K != DD || D != DD) return 0;
-  return ((size_t)bwd_grid(n_rows) * PART + (size_t)rk::kSlabMaxSeg * NRED) * sizeof(float);
+  // sized for the largest grid, so that the answer does not depend on the device queried
+  return ((size_t)kBwdMaxGrid * PART + (size_t)rk::kSlabMaxSeg * NRED) * sizeof(float);
 }
 
 int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float *alpha, float p_drop,
@@ -344,12 +562,11 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int grid = bwd_grid(n_rows);
-  const int32_t tiles = (int32_t)rk::ceil_div(n_rows, BBM);
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
   if (alpha)
-    dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, lo, hi, G, n_rows, tiles, dX, (float *)ws);
+    dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, lo, hi, G, n_rows, dX, (float *)ws);
   else
-    dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, lo, hi, G, n_rows, tiles, dX, (float *)ws);
+    dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, lo, hi, G, n_rows, dX, (float *)ws);
   RK_CHECK_LAUNCH("dense_bwd_kernel");
   float *tmp = (float *)ws + (size_t)grid * PART;
   const int n_seg = rk::slab_segments(grid);
