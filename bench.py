@@ -34,6 +34,7 @@ from recommend_amd.graph_constructor import GraphConstructor  # noqa: E402
 from recommend_amd.loss import gather_dot_bpr_loss  # noqa: E402
 from recommend_amd.model import ModelFactory  # noqa: E402
 from recommend_amd.sampler import NegativeSampler, TrainBatchLoader, build_user_csr  # noqa: E402
+from recommend_amd.train_step import GraphedTrainStep  # noqa: E402
 
 METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
 K_LIST = [5, 10, 20]
@@ -238,27 +239,25 @@ def main():
 
     # ---------------------------------------------------------------- one training epoch
     epoch = None
-    last_batch = {}
     if args.epoch_steps != 0 and world == 1:
         p_ptr, p_items = build_user_csr(data.users, data.items, U)
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
         dp, di = sampler.device_csr(dev)
         loader = TrainBatchLoader(tu, ti, tr, BATCH[args.shape], sampler, device=dev, resolve_on_host=False)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
         model.train()
         n_steps = len(loader) if args.epoch_steps < 0 else min(args.epoch_steps, len(loader))
         it = iter(loader)
+        # the step (forward, BPR loss with in-kernel negative lookup, backward, clip, Adam) is
+        # captured once as a HIP graph and replayed per batch
+        first = next(it)
+        stepper = GraphedTrainStep(model, opt, gather_dot_bpr_loss, first,
+                                   constants={"pos_ptr": dp, "pos_items": di}, max_grad_norm=1.0)
+        pending = [first]
 
         def train_step():
-            batch = next(it)
-            batch["pos_ptr"], batch["pos_items"] = dp, di
-            opt.zero_grad(set_to_none=True)
-            loss = gather_dot_bpr_loss(model(batch), batch)
-            last_batch.update(batch)     # (the loss call fills in the negatives it resolved)
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-            opt.step()
-            return loss
+            batch = pending.pop() if pending else next(it)
+            return stepper(batch)
         for _ in range(3):
             train_step()
         torch.cuda.synchronize()
@@ -287,7 +286,11 @@ def main():
         if epoch is not None:
             from oracle import graph_oracle
             coo = graph_oracle.build_coo_vectorized(tu, ti, tr, U, I, True)
-            ms_hop, ms_step = cpu_baseline_train(model, feats, coo, last_batch, U, I)
+            B = BATCH[args.shape]     # any batch of the right size times the same work
+            cpu_batch = {"user_ids": torch.from_numpy(tu[:B].astype(np.int64)),
+                         "item_ids": torch.from_numpy(ti[:B].astype(np.int64)),
+                         "neg_items": torch.randint(0, I, (B, 1))}
+            ms_hop, ms_step = cpu_baseline_train(model, feats, coo, cpu_batch, U, I)
             cpu["spmm_hop_ms"] = round(ms_hop, 3)
             cpu["train_step_ms"] = round(ms_step, 1)
             cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \

@@ -153,14 +153,18 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
  * (Main_Model.py:162-163):
  *   Y = dropout(prelu(X1 W1^T [+ X2 W2^T] + b1 [+ b2], alpha), p) [+ R]
  * alpha == NULL: no activation.  p_drop == 0: no dropout.  Dropout keeps element
- * (row, col) iff a counter hash of (seed, row*D+col) is >= p; survivors are scaled
- * by 1/(1-p) (same distribution as nn.Dropout, different random stream).
+ * (row, col) iff a 16-bit field of a counter hash of (seed, row, col) is >=
+ * round(p * 65536); survivors are scaled by 1/(1-p) (same distribution as
+ * nn.Dropout, different random stream).  seed_step (device pointer, may be NULL):
+ * a step counter mixed into the seed when the kernel runs, so that a launch
+ * replayed from a captured HIP graph draws a new mask every step; forward and
+ * backward of one layer must see the same seed and the same counter value.
  * W: D x K (nn.Linear layout).  Built for K = D = 64. */
 int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2,
                      const float *W2, const float *b1, const float *b2,
                      const float *alpha, float p_drop, uint64_t seed,
-                     const float *residual, int64_t n_rows, int32_t K, int32_t D,
-                     float *Y, void *stream);
+                     const uint64_t *seed_step, const float *residual,
+                     int64_t n_rows, int32_t K, int32_t D, float *Y, void *stream);
 size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D);
 /* Backward of the single-input layer for upstream gradient G (the residual's
  * gradient is G itself): recomputes Z = X W^T + b and the dropout mask, writes
@@ -168,9 +172,9 @@ size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D);
  * two-input linear layer is differentiated with one call per input. */
 int rk_dense_bwd_f32(const float *X, const float *W, const float *b,
                      const float *alpha, float p_drop, uint64_t seed,
-                     const float *G, int64_t n_rows, int32_t K, int32_t D,
-                     float *dX, float *dW, float *db, float *dalpha, void *ws,
-                     size_t ws_bytes, void *stream);
+                     const uint64_t *seed_step, const float *G, int64_t n_rows,
+                     int32_t K, int32_t D, float *dX, float *dW, float *db,
+                     float *dalpha, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
 /* Replaces GraphDataLoader._generate_negative_samples,

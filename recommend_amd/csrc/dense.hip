@@ -128,10 +128,10 @@ __device__ __forceinline__ void load_w_row(const float *__restrict__ W, int row,
 
 // ------------------------------------------------------------------ forward
 template <bool DUAL, bool HAS_R>
-__global__ __launch_bounds__(256, DUAL ? 1 : 2) void dense_fwd_kernel(
+__global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
     const float *__restrict__ X1, const float *__restrict__ W1, const float *__restrict__ X2,
     const float *__restrict__ W2, const float *__restrict__ b1, const float *__restrict__ b2,
-    const float *__restrict__ alpha, float p_drop, uint32_t seed_lo, uint32_t seed_hi,
+    const float *__restrict__ alpha, float p_drop, uint64_t seed, const uint64_t *__restrict__ seed_step,
     const float *__restrict__ R, int64_t n_rows, float *__restrict__ Y) {
   // separate arrays: a DMA into one is known not to alias reads of the other
   __shared__ __attribute__((aligned(1024))) float xa[4][WT * DD];
@@ -139,6 +139,10 @@ __global__ __launch_bounds__(256, DUAL ? 1 : 2) void dense_fwd_kernel(
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
   const int64_t n_tiles = (n_rows + WT - 1) / WT;
+  // the per-call seed, advanced by a step counter in device memory when one is given (a launch
+  // replayed from a captured graph then still draws a fresh mask every step)
+  const uint64_t sd = seed + (seed_step ? seed_step[0] * 0x9E3779B97F4A7C15ull : 0ull);
+  const uint32_t seed_lo = (uint32_t)sd, seed_hi = (uint32_t)(sd >> 32);
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   if (tile >= n_tiles) return;   // wave-uniform; there is no workgroup barrier below
@@ -258,7 +262,7 @@ constexpr int PART = DD * DD + DD + 8;        // per-workgroup partial: dW, db, 
 template <bool ACT>
 __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ b,
-    const float *__restrict__ alpha, float p_drop, uint32_t seed_lo, uint32_t seed_hi,
+    const float *__restrict__ alpha, float p_drop, uint64_t seed, const uint64_t *__restrict__ seed_step,
     const float *__restrict__ G, int64_t n_rows, float *__restrict__ dX, float *__restrict__ part) {
   __shared__ __attribute__((aligned(1024))) float x0[4][WT * DD];   // X tiles, double buffered:
   __shared__ __attribute__((aligned(1024))) float x1[4][WT * DD];   // the tile is read again for dW
@@ -267,6 +271,10 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
   const int64_t n_tiles = (n_rows + WT - 1) / WT;
+  // the per-call seed, advanced by a step counter in device memory when one is given (a launch
+  // replayed from a captured graph then still draws a fresh mask every step)
+  const uint64_t sd = seed + (seed_step ? seed_step[0] * 0x9E3779B97F4A7C15ull : 0ull);
+  const uint32_t seed_lo = (uint32_t)sd, seed_hi = (uint32_t)(sd >> 32);
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
 
@@ -495,9 +503,10 @@ inline int cu_count() {
   return cached;
 }
 
-// persistent grids: forward two workgroups per CU, backward one (its kernel needs the register file)
+// Persistent grids: one workgroup per CU.  More resident wavefronts measured slower (fewer tiles
+// per wavefront to spread the weight-fragment prologue over, coarser tile quantisation).
 inline int fwd_grid(int64_t n_rows) {
-  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), 2 * (int64_t)cu_count());
+  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), (int64_t)cu_count());
 }
 constexpr int kBwdMaxGrid = 512;
 inline int bwd_grid(int64_t n_rows) {
@@ -511,8 +520,8 @@ extern "C" {
 
 int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const float *W2,
                      const float *b1, const float *b2, const float *alpha, float p_drop,
-                     uint64_t seed, const float *residual, int64_t n_rows, int32_t K, int32_t D,
-                     float *Y, void *stream) {
+                     uint64_t seed, const uint64_t *seed_step, const float *residual, int64_t n_rows,
+                     int32_t K, int32_t D, float *Y, void *stream) {
   RK_CHECK_ARG(n_rows >= 0, "negative row count");
   if (K != DD || D != DD)
     return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_fwd_f32: only 64 -> 64 layers are built (got %d -> %d)", K, D);
@@ -525,18 +534,17 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)fwd_grid(n_rows);
-  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
   if (X2) {
     if (residual)
-      dense_fwd_kernel<true, true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, lo, hi, residual, n_rows, Y);
+      dense_fwd_kernel<true, true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, seed, seed_step, residual, n_rows, Y);
     else
-      dense_fwd_kernel<true, false><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, lo, hi, nullptr, n_rows, Y);
+      dense_fwd_kernel<true, false><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, seed, seed_step, nullptr, n_rows, Y);
   } else {
     if (residual)
-      dense_fwd_kernel<false, true><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, lo, hi,
+      dense_fwd_kernel<false, true><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, seed, seed_step,
                                                            residual, n_rows, Y);
     else
-      dense_fwd_kernel<false, false><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, lo, hi,
+      dense_fwd_kernel<false, false><<<grid, 256, 0, st>>>(X1, W1, nullptr, nullptr, b1, nullptr, alpha, p_drop, seed, seed_step,
                                                             nullptr, n_rows, Y);
   }
   RK_CHECK_LAUNCH("dense_fwd_kernel");
@@ -550,7 +558,8 @@ size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D) {
 }
 
 int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float *alpha, float p_drop,
-                     uint64_t seed, const float *G, int64_t n_rows, int32_t K, int32_t D, float *dX,
+                     uint64_t seed, const uint64_t *seed_step, const float *G, int64_t n_rows, int32_t K,
+                     int32_t D, float *dX,
                      float *dW, float *db, float *dalpha, void *ws, size_t ws_bytes, void *stream) {
   RK_CHECK_ARG(n_rows > 0, "empty layer input");
   if (K != DD || D != DD)
@@ -562,11 +571,10 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int grid = bwd_grid(n_rows);
-  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
   if (alpha)
-    dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, lo, hi, G, n_rows, dX, (float *)ws);
+    dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
   else
-    dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, lo, hi, G, n_rows, dX, (float *)ws);
+    dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
   RK_CHECK_LAUNCH("dense_bwd_kernel");
   float *tmp = (float *)ws + (size_t)grid * PART;
   const int n_seg = rk::slab_segments(grid);

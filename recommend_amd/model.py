@@ -151,8 +151,9 @@ class TESTModel(nn.Module):
         self.alphas = torch.randn(self.modal_num, requires_grad=True, device=device)
         # Main_Model.py:78-79,98: the id embedding the network reads is the first table's
         # weight; the table registered afterwards is a separate parameter
-        first = nn.Embedding(self.num_nodes, emb_dim, device=device)
-        self.embs = first.weight.unsqueeze(0).expand(self.modal_num, -1, -1)
+        # (kept as a bare leaf tensor and expanded per forward: a view built once here would keep
+        # its autograd nodes, and the stream they were created on, alive across steps)
+        self._first_emb = nn.Embedding(self.num_nodes, emb_dim, device=device).weight
 
         self.test = TEST(modal_num=self.modal_num, emb_num=emb_dim, layer_num=layer_num,
                          dropout=dropout)
@@ -169,6 +170,11 @@ class TESTModel(nn.Module):
         self._initialize_parameters()
         self._graph_cache = None
         self._graph_features_cache = None
+
+    @property
+    def embs(self):
+        """Main_Model.py:79: the first embedding table's weight, once per modality."""
+        return self._first_emb.unsqueeze(0).expand(self.modal_num, -1, -1)
 
     def _initialize_parameters(self):
         for module in self.modules():

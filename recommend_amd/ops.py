@@ -314,6 +314,22 @@ def next_dropout_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
 
 
+_dropout_step = {}
+
+
+def set_dropout_step_tensor(t):
+    """Register (or clear, with None) a one-element int64 CUDA tensor that the layer kernels
+    mix into their dropout seeds at run time.  A training step captured in a HIP graph keeps
+    the seeds it was captured with; bumping this counter inside the graph gives every replay
+    its own masks."""
+    if t is None:
+        _dropout_step.clear()
+        return
+    if not (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1):
+        raise ValueError("the dropout step counter is a one-element int64 CUDA tensor")
+    _dropout_step[t.device] = t
+
+
 def dense_supported(x, weight):
     return x.is_cuda and x.dim() == 2 and tuple(weight.shape) == (64, 64) and x.shape[1] == 64
 
@@ -337,9 +353,11 @@ class _Dense(torch.autograd.Function):
         n, K = x1.shape
         D = w1.shape[0]
         y = torch.empty((n, D), dtype=torch.float32, device=x1.device)
+        step = _dropout_step.get(x1.device) if p > 0.0 else None
         _ffi.call("rk_dense_fwd_f32", ptr(x1), ptr(w1), ptr(x2), ptr(w2), ptr(b1), ptr(b2), ptr(alpha_c),
-                  c_float(p), _ffi.c_uint64(seed), ptr(residual), c_int64(n), c_int32(K), c_int32(D),
-                  ptr(y), stream_ptr(y.device))
+                  c_float(p), _ffi.c_uint64(seed), ptr(step), ptr(residual), c_int64(n), c_int32(K),
+                  c_int32(D), ptr(y), stream_ptr(y.device))
+        ctx.step = step
         ctx.save_for_backward(x1, w1, b1, x2, w2, alpha_c)
         ctx.p, ctx.seed = p, seed
         ctx.has = (b1 is not None, b2 is not None, residual is not None)
@@ -362,7 +380,7 @@ class _Dense(torch.autograd.Function):
             db = torch.empty(D, dtype=torch.float32, device=dev)
             da = torch.empty(1, dtype=torch.float32, device=dev) if al is not None else None
             _ffi.call("rk_dense_bwd_f32", ptr(x), ptr(w), ptr(b), ptr(al), c_float(ctx.p),
-                      _ffi.c_uint64(ctx.seed), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw),
+                      _ffi.c_uint64(ctx.seed), ptr(ctx.step), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw),
                       ptr(db), ptr(da), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(dev))
             return dx, dw, db, da
 

@@ -1,0 +1,75 @@
+"""One MMFCN training step as a captured HIP graph.
+
+The reference's step (train/graph_trainer.py:140-157: zero_grad, forward, loss, backward,
+clip_grad_norm_, optimizer.step) launches a few hundred small kernels; issued one by one from
+Python the step is bound by the host, not by the GPU.  `GraphedTrainStep` records the whole step
+once with torch.cuda.graphs (hipGraph underneath) and replays it per batch: the batch is copied
+into fixed device buffers, the dropout masks advance through a step counter in device memory,
+and the only host work per step is one graph launch.
+
+Batches whose size differs from the captured one (the last batch of an epoch) run eagerly.
+"""
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
+                 loss_fn: Callable[[Dict, Dict], torch.Tensor], example_batch: Dict[str, torch.Tensor],
+                 constants: Optional[Dict[str, torch.Tensor]] = None,
+                 max_grad_norm: Optional[float] = 1.0, warmup_steps: int = 3):
+        """example_batch: a batch dict as the loader yields it (device tensors); its tensors fix
+        the captured shapes, and the warm-up steps train on it (they are real steps).  constants: entries every batch carries unchanged (e.g. the
+        user->positives CSR for in-kernel negative lookup); they are not copied per step.
+        The optimizer must be capturable (e.g. Adam(capturable=True))."""
+        if warmup_steps < 1:
+            # optimizers create their state on the first step; created inside the capture it would
+            # be re-zeroed by every replay
+            raise ValueError("at least one eager warm-up step is needed before the capture")
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.max_grad_norm = max_grad_norm
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = next(iter(example_batch.values())).device
+        self.constants = dict(constants or {})
+        self.static = {k: v.clone() for k, v in example_batch.items() if k not in self.constants}
+        self.shapes = {k: tuple(v.shape) for k, v in self.static.items()}
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.set_dropout_step_tensor(self.step_counter)
+        self.graph = None
+        # warm-up on a side stream, as graph capture requires (allocator pools, lazy state)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup_steps):
+                self._eager(self.static)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._body({**self.static, **self.constants})
+
+    def _body(self, batch):
+        self.step_counter.add_(1)
+        loss = self.loss_fn(self.model(batch), batch)
+        loss.backward()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+        self.opt.step()
+        return loss.detach()
+
+    def _eager(self, batch):
+        self.opt.zero_grad(set_to_none=True)
+        return self._body({**batch, **self.constants})
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Runs one step on `batch`; returns the loss (a device scalar that the next call
+        overwrites)."""
+        if self.graph is None or any(tuple(batch[k].shape) != self.shapes[k] for k in self.shapes):
+            return self._eager(batch)
+        for k, dst in self.static.items():
+            dst.copy_(batch[k], non_blocking=True)
+        self.graph.replay()
+        return self.static_loss

@@ -92,3 +92,54 @@ def test_training_steps_reduce_loss():
     assert np.mean(losses[-n:]) < np.mean(losses[:n])
     grads = [q.grad for q in model.parameters() if q.grad is not None]
     assert len(grads) > 10
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """The captured step replays the same arithmetic as the eager step (dropout off), and with
+    dropout on every replay draws a different mask."""
+    from recommend_amd.train_step import GraphedTrainStep
+    from recommend_amd import ops
+    U, I, D = 300, 200, 64
+
+    def setup(dropout):
+        model, d, feats, (tu, ti, tr) = build_model(U, I, D, 4000, dropout, seed=5)
+        p, it = build_user_csr(d.users, d.items, U)
+        sampler = NegativeSampler(p, it, I, seed=7)
+        dp, di = sampler.device_csr(DEV)
+        loader = TrainBatchLoader(tu, ti, tr, 256, sampler, shuffle=False, device=DEV, resolve_on_host=False)
+        batches = [b for b in loader if b["user_ids"].shape[0] == 256][:6]
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        model.train()
+        return model, opt, batches, {"pos_ptr": dp, "pos_items": di}
+
+    try:
+        m1, o1, batches, consts = setup(0.0)
+        eager = []
+        for b in [batches[0]] + batches:     # the stepper's warm-up step trains on the first batch
+            b = {**b, **consts}
+            o1.zero_grad(set_to_none=True)
+            loss = gather_dot_bpr_loss(m1(b), b)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
+            o1.step()
+            eager.append(float(loss))
+        m2, o2, batches2, consts2 = setup(0.0)
+        st = GraphedTrainStep(m2, o2, gather_dot_bpr_loss, batches2[0], constants=consts2, warmup_steps=1)
+        graphed = [float(st(b)) for b in batches2]
+        np.testing.assert_allclose(graphed, eager[1:], rtol=2e-4)
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            # (Adam divides by sqrt(v): entries with near-zero gradients amplify the float-atomic
+            # ordering noise of the loss backward, hence the absolute tolerance of a fraction of lr)
+            torch.testing.assert_close(p2, p1, rtol=0, atol=5e-3, msg=n1)
+        # dropout on: the same batch replayed twice gives different losses (fresh masks), and
+        # the counter advanced once per step
+        m3, o3, batches3, consts3 = setup(0.5)
+        for g in o3.param_groups:
+            g["lr"] = 0.0
+        st3 = GraphedTrainStep(m3, o3, gather_dot_bpr_loss, batches3[0], constants=consts3, warmup_steps=1)
+        c0 = int(st3.step_counter)
+        a, b_ = float(st3(batches3[0])), float(st3(batches3[0]))
+        assert a != b_
+        assert int(st3.step_counter) == c0 + 2
+    finally:
+        ops.set_dropout_step_tensor(None)
