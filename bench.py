@@ -244,7 +244,7 @@ def main():
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
         dp, di = sampler.device_csr(dev)
         loader = TrainBatchLoader(tu, ti, tr, BATCH[args.shape], sampler, device=dev, resolve_on_host=False)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
         model.train()
         n_steps = len(loader) if args.epoch_steps < 0 else min(args.epoch_steps, len(loader))
         it = iter(loader)

@@ -8,18 +8,44 @@ namespace {
 using rk::kWave;
 
 // ------------------------------------------------------------- G2 ---------
+// Rows up to kLongRow edges: one thread per row, edges summed in CSR (= edge id) order.  Longer
+// rows (popular items reach 10^5 edges) would serialise a whole launch behind one thread, so a
+// second launch gives each of them a wavefront: lane-strided partial sums folded by a fixed
+// shuffle tree.  Both orders give the same bits whenever the sum is exact in fp32 (integer
+// ratings, the case the reference's data produces); otherwise they differ in the last place.
+constexpr int32_t kLongRow = 512;
+
 __global__ void in_weight_sqrt_kernel(const int32_t *__restrict__ rowptr,
                                       const int32_t *__restrict__ eid,
                                       const float *__restrict__ w_coo, int32_t n,
                                       float *__restrict__ sq) {
   const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
+  const int32_t lo = rowptr[v], hi = rowptr[v + 1];
+  if (hi - lo > kLongRow) return;
   float s = 0.0f;
-  for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) s += w_coo[eid[p]];
+  for (int32_t p = lo; p < hi; ++p) s += w_coo[eid[p]];
   // torch.clamp(min=1e-12).sqrt(), graph_constructor.py:178
   sq[v] = sqrtf(fmaxf(s, 1e-12f));
 }
 
+__global__ __launch_bounds__(256) void in_weight_sqrt_long_kernel(const int32_t *__restrict__ rowptr,
+                                                                  const int32_t *__restrict__ eid,
+                                                                  const float *__restrict__ w_coo, int32_t n,
+                                                                  float *__restrict__ sq) {
+  const int32_t v = blockIdx.x * 4 + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (v >= n) return;
+  const int32_t lo = rowptr[v], hi = rowptr[v + 1];
+  if (hi - lo <= kLongRow) return;
+  float s = 0.0f;
+  for (int32_t p = lo + lane; p < hi; p += kWave) s += w_coo[eid[p]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+  if (lane == 0) sq[v] = sqrtf(fmaxf(s, 1e-12f));
+}
+
+// w / (in_w[src] * in_w[dst]), graph_constructor.py:186: independent per edge
 __global__ void sym_norm_kernel(const int32_t *__restrict__ rowptr,
                                 const int32_t *__restrict__ col,
                                 const int32_t *__restrict__ eid,
@@ -28,10 +54,29 @@ __global__ void sym_norm_kernel(const int32_t *__restrict__ rowptr,
                                 float *__restrict__ w_norm) {
   const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
+  const int32_t lo = rowptr[v], hi = rowptr[v + 1];
+  if (hi - lo > kLongRow) return;
   const float sv = sq[v];
-  for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+  for (int32_t p = lo; p < hi; ++p) {
     const int32_t e = eid[p];
-    // w / (in_w[src] * in_w[dst]), graph_constructor.py:186
+    w_norm[e] = w_coo[e] / (sq[col[p]] * sv);
+  }
+}
+
+__global__ __launch_bounds__(256) void sym_norm_long_kernel(const int32_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ col,
+                                                            const int32_t *__restrict__ eid,
+                                                            const float *__restrict__ w_coo,
+                                                            const float *__restrict__ sq, int32_t n,
+                                                            float *__restrict__ w_norm) {
+  const int32_t v = blockIdx.x * 4 + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (v >= n) return;
+  const int32_t lo = rowptr[v], hi = rowptr[v + 1];
+  if (hi - lo <= kLongRow) return;
+  const float sv = sq[v];
+  for (int32_t p = lo + lane; p < hi; p += kWave) {
+    const int32_t e = eid[p];
     w_norm[e] = w_coo[e] / (sq[col[p]] * sv);
   }
 }
@@ -44,14 +89,17 @@ __global__ void deg_pow_kernel(const int32_t *__restrict__ rowptr, int32_t n,
   dinv[v] = powf((float)(rowptr[v + 1] - rowptr[v]), -0.5f);
 }
 
-__global__ void deg_norm_kernel(const int32_t *__restrict__ rowptr,
-                                const int32_t *__restrict__ col,
-                                const int32_t *__restrict__ eid,
-                                int32_t n, float *__restrict__ w_norm) {
-  const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per destination row, lanes over its edges (independent per edge)
+__global__ __launch_bounds__(256) void deg_norm_kernel(const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col,
+                                                       const int32_t *__restrict__ eid,
+                                                       int32_t n, float *__restrict__ w_norm) {
+  const int32_t v = blockIdx.x * 4 + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
   if (v >= n) return;
-  const float dv = powf((float)(rowptr[v + 1] - rowptr[v]), -0.5f);
-  for (int32_t p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+  const int32_t lo = rowptr[v], hi = rowptr[v + 1];
+  const float dv = powf((float)(hi - lo), -0.5f);
+  for (int32_t p = lo + lane; p < hi; p += kWave) {
     const int32_t u = col[p];
     const float du = powf((float)(rowptr[u + 1] - rowptr[u]), -0.5f);
     w_norm[eid[p]] = du * dv;
@@ -77,10 +125,15 @@ int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
   if (n_nodes == 0) return RK_OK;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)rk::ceil_div(n_nodes, 256);
+  const int wblocks = (int)rk::ceil_div(n_nodes, 4);
   in_weight_sqrt_kernel<<<blocks, 256, 0, st>>>(rowptr, eid, w_coo, n_nodes, sqrt_in_w);
   RK_CHECK_LAUNCH("in_weight_sqrt_kernel");
+  in_weight_sqrt_long_kernel<<<wblocks, 256, 0, st>>>(rowptr, eid, w_coo, n_nodes, sqrt_in_w);
+  RK_CHECK_LAUNCH("in_weight_sqrt_long_kernel");
   sym_norm_kernel<<<blocks, 256, 0, st>>>(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, w_norm_coo);
   RK_CHECK_LAUNCH("sym_norm_kernel");
+  sym_norm_long_kernel<<<wblocks, 256, 0, st>>>(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, w_norm_coo);
+  RK_CHECK_LAUNCH("sym_norm_long_kernel");
   return RK_OK;
 }
 
@@ -90,7 +143,7 @@ int rk_deg_normalize_f32(const int32_t *rowptr, const int32_t *col,
   RK_CHECK_ARG(rowptr && col && eid && w_norm_coo, "null pointer");
   RK_CHECK_ARG(n_nodes >= 0, "negative node count");
   if (n_nodes == 0) return RK_OK;
-  deg_norm_kernel<<<(int)rk::ceil_div(n_nodes, 256), 256, 0, (hipStream_t)stream>>>(
+  deg_norm_kernel<<<(int)rk::ceil_div(n_nodes, 4), 256, 0, (hipStream_t)stream>>>(
       rowptr, col, eid, n_nodes, w_norm_coo);
   RK_CHECK_LAUNCH("deg_norm_kernel");
   return RK_OK;
