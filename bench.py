@@ -230,7 +230,7 @@ def main():
     ms_spmm = event_ms(spmm_fn, 200)
     spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * D * 4
     gbs = spmm_bytes / (ms_spmm * 1e-3) / 1e9
-    roofline_spmm = {"kernel": "spmm_rows_kernel (+spmm_long_reduce_kernel)", "bound": "hbm",
+    roofline_spmm = {"kernel": "spmm_rows_kernel (+spmm_multi_reduce_kernel)", "bound": "hbm",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                      "ms_per_launch": round(ms_spmm, 5),
