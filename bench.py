@@ -39,6 +39,10 @@ from recommend_amd.train_step import GraphedTrainStep  # noqa: E402
 METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
 K_LIST = [5, 10, 20]
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+# Memory-side bytes per launch at the Elec shape from rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950
+# requires for 16-B-per-lane reads, plus WRITE_SIZE; one counter per run): profiles/r01_pmc_*.csv.
+# They are measurements of THIS shape on one GPU; other shapes report null.
+PMC_TRAFFIC_ELEC = {"score_topk": 2 * 363.0e6 + 72.2e6, "spmm": 2 * 252.3e6 + 63.9e6}
 MFMA_F32_PEAK_TFS = 157.3    # MI355X fp32 matrix peak
 BATCH = {"baby": 2048, "clothing": 1024, "sports": 256, "elec": 256}   # reference config.py presets
 
@@ -218,7 +222,9 @@ def main():
     tflops = 2.0 * U * n_loc * D / (ms_topk * 1e-3) / 1e12
     roofline = {"kernel": "score_topk_kernel (+topk_merge_kernel)", "bound": "mfma", "achieved": round(tflops, 3),
                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFS, 4),
-                "traffic": None, "ms_per_launch": round(ms_topk, 4),
+                "traffic": PMC_TRAFFIC_ELEC["score_topk"] if (args.shape == "elec" and world == 1 and D == 64) else None,
+                "traffic_unit": "B per launch (L2 memory-side requests, Infinity-Cache hits included)",
+                "ms_per_launch": round(ms_topk, 4),
                 "algorithmic": f"2*U*I*D = {2.0 * U * n_loc * D:.4g} flop per launch"}
 
     # ---------------------------------------------------------------- SpMM hop
@@ -232,7 +238,8 @@ def main():
     gbs = spmm_bytes / (ms_spmm * 1e-3) / 1e9
     roofline_spmm = {"kernel": "spmm_rows_kernel (+spmm_multi_reduce_kernel)", "bound": "hbm",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": PMC_TRAFFIC_ELEC["spmm"] if (args.shape == "elec" and D == 64) else None,
                      "ms_per_launch": round(ms_spmm, 5),
                      "algorithmic": f"nnz*8 + (N+1)*4 + 2*N*D*4 = {spmm_bytes} B per hop"}
     ms_spmm_t = event_ms(lambda: ops.spmm_raw(gc.graph.bwd, h, out=buf), 200)
