@@ -2,11 +2,13 @@
 (backend "nccl" = RCCL over xGMI on the GPU box).
 
 Full-ranking evaluation shards the ITEM table: rank r scores every user against
-items [lo_r, hi_r) only, keeps its local top-K (ids are global), the per-rank
-lists are exchanged with one all-gather of U*K*(4+4) bytes per rank, every rank
-merges the lists of its own slice of users, reduces the metric sums of that
-slice, and one all-reduce of 6*len(k_list) doubles finishes the means.  Contiguous
-item ranges keep "lower id wins" valid across shards.
+items [lo_r, hi_r) only and keeps its local top-K (ids are global).  Every rank
+then merges the lists of its own slice of users, so the exchange is one
+all-to-all: rank r sends rank q the rows of q's user slice (scores and ids packed
+in one buffer), U*K*8*(W-1)/W bytes out and in per rank; an all-gather would move W
+times as much for lists the receiver never reads.  Each rank reduces the metric
+sums of its slice and one all-reduce of 6*len(k_list) doubles finishes the means.
+Contiguous item ranges keep "lower id wins" valid across shards.
 
 The reference is single-process (no collective anywhere in its tree); this file
 has no counterpart there.  `compute` is the module that provides score_topk /
@@ -46,6 +48,21 @@ def all_reduce_tensor(t, op=dist.ReduceOp.SUM, group=None):
         return t
     dist.all_reduce(t, op=op, group=group)
     return t
+
+
+def exchange_user_slices(packed, n_users, rank, world, group=None):
+    """packed: [n_users, C] rows of every user on this rank.  Returns [world, rows_of_my_slice, C]:
+    the rows of this rank's user slice as computed by every rank (source-major)."""
+    bounds = [user_range(n_users, r, world) for r in range(world)]
+    in_split = [hi - lo for lo, hi in bounds]
+    mine = in_split[rank]
+    via_host = _via_host(group) and packed.is_cuda
+    src = packed.cpu() if via_host else packed.contiguous()
+    out = torch.empty((world * mine, packed.shape[1]), dtype=src.dtype, device=src.device)
+    dist.all_to_all_single(out, src, [mine] * world, in_split, group=group)
+    if via_host:
+        out = out.to(packed.device)
+    return out.view(world, mine, packed.shape[1])
 
 
 def item_range(n_items, rank, world):
@@ -101,12 +118,11 @@ class ShardedRankingEvaluator:
             raise ValueError("k must be in the range [1, num_items of the smallest shard]")
         st = self._state(user_embeddings.device)
         s, ids = self.local_topk(user_embeddings, item_embeddings_full, kmax)
-        # one exchange step: every rank's [U, K] lists
-        gs = all_gather_tensor(s.contiguous(), self.world, self.group)
-        gi = all_gather_tensor(ids.contiguous(), self.world, self.group)
-        sl = slice(self.u_lo, self.u_hi)
-        cand_s = torch.stack([g[sl] for g in gs], dim=1).contiguous()     # [u, world, K]
-        cand_i = torch.stack([g[sl] for g in gi], dim=1).contiguous()
+        # one exchange step: every rank receives the lists of its own user slice from every rank
+        packed = torch.cat([s.contiguous(), ids.contiguous().view(torch.float32)], dim=1)     # [U, 2K]
+        got = exchange_user_slices(packed, self.n_users, self.rank, self.world, self.group)  # [W, u, 2K]
+        cand_s = got[:, :, :kmax].permute(1, 0, 2).contiguous()                              # [u, W, K]
+        cand_i = got[:, :, kmax:].contiguous().view(torch.int32).permute(1, 0, 2).contiguous()
         sums = torch.zeros((len(self.k_list), 6), dtype=torch.float64, device=s.device)
         self.last_ids = None
         if self.u_hi > self.u_lo:
