@@ -182,11 +182,15 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b,
  * draw from CPython's process-global MT19937.  state is 625 words (624 + index).
  * rk_mt_seed follows random.seed(int) for 0 <= seed < 2^64. */
 int rk_mt_seed_host(uint32_t *state625_host, uint64_t seed);
-/* One batch: for each user in order, n = n_items - |pos(u)| candidates in
- * ascending id order; draws R ranks exactly as random.sample(cands, R) does
- * (random.choices when n < R) and writes the ranks and/or the resolved item
- * ids (either output may be NULL).  pos_ptr/pos_items: per-user sorted, unique
- * positives over the full interaction table (CSR, host). */
+/* One batch: for each user in order, the n = n_items - |pos(u)| candidates in the
+ * order list(all_items - pos(u)) has in CPython: ascending ids while set.difference
+ * copies and removes (len(all_items) >> 2 > |pos(u)|), otherwise the slot order of
+ * the freshly built hash table, which is emulated.  Draws R picks exactly as
+ * random.sample(cands, R) does (random.choices when n < R) and writes, for every
+ * pick, its rank among the candidates in ascending id order (the form the loss
+ * kernel resolves on the device) and/or the item id (either output may be NULL).
+ * pos_ptr/pos_items: per-user sorted, unique positives over the full interaction
+ * table (CSR, host). */
 int rk_neg_sample_host(uint32_t *state625_host, const int64_t *users_host,
                        int64_t B, int32_t R, const int32_t *pos_ptr_host,
                        const int32_t *pos_items_host, int32_t n_items,
@@ -275,9 +279,10 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb,
                       int32_t item_id_offset, float *out_scores,
                       int32_t *out_ids, void *ws, size_t ws_bytes,
                       void *stream);
-/* Merge P candidate lists per user (each Kin long, any order, padding entries
- * have id < 0) into the best K by (score desc, id asc).  Used for the item
- * splits inside one GPU and for the all-gathered per-GPU lists. */
+/* Merge P candidate lists per user (each Kin long, in any order, P * Kin <= 1024;
+ * padding entries have id < 0) into the best K by (score desc, id asc).  Used for
+ * the item slices inside one GPU and for the per-GPU lists of a user slice after
+ * the exchange between item-sharded ranks. */
 int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users,
                       int32_t P, int32_t Kin, int32_t K, float *out_scores,
                       int32_t *out_ids, void *stream);
