@@ -1,0 +1,100 @@
+"""GPU parity at the benchmark's full size (Elec shape: 192,403 users x 63,001 items,
+1.35 M training interactions): the oracle where it finishes in seconds, and
+size-independent properties (shard-and-merge equals unsharded, idempotence, linearity)
+everywhere else."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle, graph_oracle
+from recommend_amd import ops, synth
+from recommend_amd.evaluator import RankingEvaluator, pairs_to_csr, restrict_csr
+from recommend_amd.graph_constructor import GraphConstructor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
+
+
+@pytest.fixture(scope="module")
+def elec():
+    return synth.make_named("elec")
+
+
+def test_elec_graph_normalisation_and_hop(elec):
+    d = elec
+    u, i, r = d.split(0)
+    N, D = d.n_users + d.n_items, 64
+    gc = GraphConstructor(add_self_loops=True, normalize_adj=True)
+    gc.build_graph((u, i, r), d.n_users, d.n_items)
+    gc.move_to_device(DEV)
+    gc.creat_feature_weight(None)
+    src, dst, w = graph_oracle.build_coo_vectorized(u, i, r, d.n_users, d.n_items, True)
+    wn, _ = graph_oracle.normalize(src, dst, w, N)
+    np.testing.assert_array_equal(gc.graph.edata["weight"].cpu().numpy(), wn)     # bit-exact, hubs included
+    p, idx, _eid = graph_oracle.csr_from_coo(dst, src, N)
+    np.testing.assert_array_equal(gc.graph.fwd.rowptr.cpu().numpy(), p)
+    np.testing.assert_array_equal(gc.graph.fwd.idx.cpu().numpy(), idx)
+    assert int(np.diff(p).max()) > 2048      # the shape does exercise the multi-chunk rows
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x, y = torch.randn(N, D, generator=g), torch.randn(N, D, generator=g)
+    ax, ay = gc.propagate(x.to(DEV)), gc.propagate(y.to(DEV))
+    ref = graph_oracle.spmm_f64(src, dst, wn, x.numpy())
+    assert np.abs(ax.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+    torch.testing.assert_close(gc.propagate((2.0 * x - 0.5 * y).to(DEV)), 2.0 * ax - 0.5 * ay, rtol=1e-4, atol=1e-5)
+    assert torch.equal(gc.propagate(x.to(DEV)), ax)                              # deterministic
+    # backward operand: <A x, y> == <x, A^T y>
+    xt = x.to(DEV).requires_grad_(True)
+    (gc.propagate(xt) * y.to(DEV)).sum().backward()
+    lhs = float((ax.double() * y.to(DEV).double()).sum())
+    rhs = float((xt.grad.double() * x.to(DEV).double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+
+
+def test_elec_full_ranking(elec):
+    d = elec
+    rng = np.random.default_rng(0)
+    D, K = 64, 20
+    ue = (rng.standard_normal((d.n_users, D)) * 0.1).astype(np.float32)
+    ie = (rng.standard_normal((d.n_items, D)) * 0.1).astype(np.float32)
+    tu, ti, _ = d.split(0)
+    vu, vi, _ = d.split(1)
+    ev = RankingEvaluator((vu, vi), (tu, ti), [5, 10, 20], METRICS, n_users=d.n_users)
+    ued, ied = torch.from_numpy(ue).to(DEV), torch.from_numpy(ie).to(DEV)
+    s, ids = ev.topk(ued, ied, K)
+    s2, ids2 = ev.topk(ued, ied, K)
+    assert torch.equal(ids, ids2) and torch.equal(s, s2)
+    # the oracle on a user sample: ids and scores bit for bit
+    ptr, cols = pairs_to_csr(tu, ti, d.n_users)
+    us = np.sort(rng.choice(d.n_users, 384, replace=False))
+    sub_ptr = np.concatenate([[0], np.cumsum(ptr[us + 1] - ptr[us])]).astype(np.int32)
+    sub_cols = np.concatenate([cols[ptr[u]:ptr[u + 1]] for u in us]).astype(np.int32)
+    o_s, o_i = eval_oracle.score_topk(ue[us], ie, K, sub_ptr, sub_cols)
+    np.testing.assert_array_equal(ids.cpu().numpy()[us], o_i)
+    np.testing.assert_array_equal(s.cpu().numpy()[us], o_s)
+    # three item shards ranked separately and merged give the unsharded ranking
+    mp, mc = torch.from_numpy(ptr).to(DEV), torch.from_numpy(cols).to(DEV)
+    bounds = [0, 20001, 47000, d.n_items]
+    ps, pi = [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        p2, c2 = restrict_csr(ptr, cols, lo, hi)
+        a, b = ops.score_topk(ued, ied[lo:hi], K, torch.from_numpy(p2).to(DEV), torch.from_numpy(c2).to(DEV),
+                              item_id_offset=lo)
+        ps.append(a), pi.append(b)
+    ms, mi = ops.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), K)
+    assert torch.equal(mi, ids) and torch.equal(ms, s)
+    # masked pairs never rank; scores are sorted; ids unique per user
+    idn = ids.cpu().numpy().astype(np.int64)
+    train_keys = np.repeat(np.arange(d.n_users), np.diff(ptr)).astype(np.int64) * d.n_items + cols
+    got_keys = (np.arange(d.n_users, dtype=np.int64)[:, None] * d.n_items + idn).ravel()
+    assert not np.isin(got_keys, train_keys).any()
+    sn = s.cpu().numpy()
+    assert (np.diff(sn, axis=1) <= 0).all()
+    assert (np.sort(idn, axis=1)[:, 1:] != np.sort(idn, axis=1)[:, :-1]).all()
+    # metrics: device reduction against the oracle's on the device's ids
+    res = ev.evaluate(ued, ied)
+    tp, tc = pairs_to_csr(vu, vi, d.n_users)
+    want = eval_oracle.metrics_from_topk_sparse(idn.astype(np.int32), tp, tc, [5, 10, 20])
+    for k in (5, 10, 20):
+        for m in METRICS:
+            assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)
