@@ -56,9 +56,23 @@ class GraphedTrainStep:
         loss = self.loss_fn(self.model(batch), batch)
         loss.backward()
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+            self._clip()
         self.opt.step()
         return loss.detach()
+
+    def _clip(self):
+        """clip_grad_norm_(params, max_norm) (train/graph_trainer.py:154).  With a fused optimizer the
+        scaling rides on the optimizer kernel's gradient-scale input (grad /= scale inside the
+        update) instead of one multiply launch per parameter."""
+        if not self.opt.defaults.get("fused"):
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+        # clip_coef = min(1, max_norm / (total + 1e-6)); the optimizer divides by its inverse
+        self.opt.grad_scale = torch.clamp((total + 1e-6) / self.max_grad_norm, min=1.0).reshape(())
+        if getattr(self.opt, "found_inf", None) is None:
+            self.opt.found_inf = torch.zeros((), dtype=torch.float32, device=total.device)
 
     def _eager(self, batch):
         self.opt.zero_grad(set_to_none=True)

@@ -101,14 +101,14 @@ def test_graphed_train_step_matches_eager_steps():
     from recommend_amd import ops
     U, I, D = 300, 200, 64
 
-    def setup(dropout):
+    def setup(dropout, fused=False):
         model, d, feats, (tu, ti, tr) = build_model(U, I, D, 4000, dropout, seed=5)
         p, it = build_user_csr(d.users, d.items, U)
         sampler = NegativeSampler(p, it, I, seed=7)
         dp, di = sampler.device_csr(DEV)
         loader = TrainBatchLoader(tu, ti, tr, 256, sampler, shuffle=False, device=DEV, resolve_on_host=False)
         batches = [b for b in loader if b["user_ids"].shape[0] == 256][:6]
-        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=fused)
         model.train()
         return model, opt, batches, {"pos_ptr": dp, "pos_items": di}
 
@@ -123,7 +123,7 @@ def test_graphed_train_step_matches_eager_steps():
             torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
             o1.step()
             eager.append(float(loss))
-        m2, o2, batches2, consts2 = setup(0.0)
+        m2, o2, batches2, consts2 = setup(0.0, fused=True)    # clipping folded into the fused update
         st = GraphedTrainStep(m2, o2, gather_dot_bpr_loss, batches2[0], constants=consts2, warmup_steps=1)
         graphed = [float(st(b)) for b in batches2]
         np.testing.assert_allclose(graphed, eager[1:], rtol=2e-4)
