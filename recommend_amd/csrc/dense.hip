@@ -340,6 +340,29 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
         }
     }
 
+    // A tile whose upstream gradient is all zero contributes nothing to dW, db, d(alpha) and has
+    // dX = 0: the loss touches a few hundred rows, and until the first hop of the backward pass
+    // spreads them, the row-wise layers see exactly those rows.  (-0.0 counts as zero.)
+    {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= __float_as_uint(dz[t][r]);
+      if (!__any((bits << 1) != 0u)) {
+        if (dX) {
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            float *dxp = dX + row0 * DD + 32 * kt + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (full || row0 + crow(r, half) < n_rows) dxp[crow(r, half) * DD] = 0.0f;
+          }
+        }
+        return;
+      }
+    }
+
     floatx16 z[2];
     if constexpr (ACT) {
 #pragma unroll

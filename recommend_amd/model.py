@@ -153,7 +153,9 @@ class TESTModel(nn.Module):
         # weight; the table registered afterwards is a separate parameter
         # (kept as a bare leaf tensor and expanded per forward: a view built once here would keep
         # its autograd nodes, and the stream they were created on, alive across steps)
-        self._first_emb = nn.Embedding(self.num_nodes, emb_dim, device=device).weight
+        # a plain tensor, not a Parameter: assigning a Parameter would register it, and the reference's
+        # first table is replaced as a submodule (Main_Model.py:98) and so is never handed to the optimizer
+        self._first_emb = nn.Embedding(self.num_nodes, emb_dim, device=device).weight.detach().requires_grad_(True)
 
         self.test = TEST(modal_num=self.modal_num, emb_num=emb_dim, layer_num=layer_num,
                          dropout=dropout)
