@@ -220,7 +220,9 @@ class TESTModel(nn.Module):
 
         self.Xs = [self._project(linear, x, is_item)
                    for linear, x, is_item in zip(self.linears, self.feats, self._feat_is_item)]
-        node_embeddings = self.test(g, self.Xs, self.embs, self.ks, self.alphas)
+        # every modality reads the same table: handing over the tensor itself (not slices of the
+        # expanded view `embs`) makes autograd add the two gradients instead of materialising [M, N, D]
+        node_embeddings = self.test(g, self.Xs, [self._first_emb] * self.modal_num, self.ks, self.alphas)
         # dropout(final_projection(.)), Main_Model.py:162-163
         node_embeddings = fused.linear_act(self.final_projection, node_embeddings, None, self.dropout)
         return {

@@ -311,7 +311,8 @@ _seed_counter = itertools.count(1)
 def next_dropout_seed():
     """64-bit seed for one dropout call: torch's seed mixed with a call counter, so a run
     re-seeded with torch.manual_seed reproduces its masks."""
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+    # (63 bits: autograd tooling that records call arguments expects them to fit an int64)
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
 
 
 _dropout_step = {}
