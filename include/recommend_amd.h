@@ -176,6 +176,21 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b,
                      int32_t K, int32_t D, float *dX, float *dW, float *db,
                      float *dalpha, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- W2: modality-weighted sum (device) ---------------------------------- */
+/* Replaces torch.sum(torch.stack(modal_features) * softmax(alphas)[:, None, None], 0),
+ * model/test/out_Layer.py:52-54, and its autograd: out = sum_m softmax(alphas)_m F_m
+ * over M <= 4 matrices of n_elem floats each (n_elem % 4 == 0).  F_host / dF_host are
+ * HOST arrays of M device pointers (a dF entry may be NULL).  Backward writes
+ * dF_m = softmax(alphas)_m * G and dalpha[M] (gradient w.r.t. the raw alphas). */
+int rk_modal_sum_fwd_f32(const float *const *F_host, int32_t M,
+                         const float *alphas, int64_t n_elem, float *out,
+                         void *stream);
+size_t rk_modal_sum_bwd_ws_bytes(void);
+int rk_modal_sum_bwd_f32(const float *const *F_host, float *const *dF_host,
+                         int32_t M, const float *alphas, const float *G,
+                         int64_t n_elem, float *dalpha, void *ws, size_t ws_bytes,
+                         void *stream);
+
 /* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
 /* Replaces GraphDataLoader._generate_negative_samples,
  * data/graph_data_loader.py:355-397, whose random.sample / random.choices calls

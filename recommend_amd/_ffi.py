@@ -68,6 +68,9 @@ SIGNATURES = {
     "rk_dense_bwd_ws_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "rk_dense_bwd_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
                                    P, P, P, P, P, c_size_t, P]),
+    "rk_modal_sum_fwd_f32": (c_int32, [P, c_int32, P, c_int64, P, P]),
+    "rk_modal_sum_bwd_ws_bytes": (c_size_t, []),
+    "rk_modal_sum_bwd_f32": (c_int32, [P, P, c_int32, P, P, c_int64, P, P, c_size_t, P]),
     "rk_mt_seed_host": (c_int32, [P, c_uint64]),
     "rk_neg_sample_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P]),
     "rk_bpr_ws_bytes": (c_size_t, [c_int64, c_int32]),

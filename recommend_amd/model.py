@@ -91,6 +91,8 @@ class TEST(nn.Module):
     def forward(self, g, Xs, embs, ks, alphas):
         modal_features = [self.MGCNs[i](g, Xs[i], embs[i], ks[i]) for i in range(self.modal_num)]
         # sum_m softmax(alphas)_m * F_m (out_Layer.py:52-54) without stacking the modalities
+        if ops.modal_sum_supported(modal_features, alphas):
+            return ops.modal_sum(modal_features, alphas)
         new_alphas = torch.softmax(alphas, dim=0)
         out = modal_features[0] * new_alphas[0]
         for i in range(1, self.modal_num):

@@ -405,6 +405,48 @@ def dense(x, weight, bias=None, alpha=None, p=0.0, residual=None, x2=None, weigh
     return y
 
 
+class _ModalSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alphas, *feats):
+        _need_cuda(alphas, *feats)
+        feats = [_f32c(f) for f in feats]
+        alphas_c = _f32c(alphas)
+        M, n = len(feats), feats[0].numel()
+        out = torch.empty_like(feats[0])
+        arr = (ctypes.c_void_p * M)(*[f.data_ptr() for f in feats])
+        _ffi.call("rk_modal_sum_fwd_f32", arr, c_int32(M), ptr(alphas_c), c_int64(n), ptr(out),
+                  stream_ptr(out.device))
+        ctx.save_for_backward(alphas_c, *feats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        alphas, *feats = ctx.saved_tensors
+        g = _f32c(g)
+        M, n = len(feats), feats[0].numel()
+        need = ctx.needs_input_grad
+        dfs = [torch.empty_like(f) if need[1 + m] else None for m, f in enumerate(feats)]
+        dalpha = torch.empty(M, dtype=torch.float32, device=g.device)
+        lib = _ffi.load()
+        ws = torch.empty(lib.rk_modal_sum_bwd_ws_bytes() // 4, dtype=torch.float32, device=g.device)
+        farr = (ctypes.c_void_p * M)(*[f.data_ptr() for f in feats])
+        darr = (ctypes.c_void_p * M)(*[(d.data_ptr() if d is not None else None) for d in dfs])
+        _ffi.call("rk_modal_sum_bwd_f32", farr, darr, c_int32(M), ptr(alphas), ptr(g), c_int64(n), ptr(dalpha),
+                  ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(g.device))
+        return (dalpha if need[0] else None, *dfs)
+
+
+def modal_sum_supported(feats, alphas):
+    return (1 <= len(feats) <= 4 and alphas.dim() == 1 and alphas.numel() == len(feats) and alphas.is_cuda
+            and all(f.is_cuda and f.dtype == torch.float32 and f.shape == feats[0].shape for f in feats)
+            and feats[0].numel() % 4 == 0)
+
+
+def modal_sum(feats, alphas):
+    """sum_m softmax(alphas)_m * feats[m] (model/test/out_Layer.py:52-54) in one pass."""
+    return _ModalSum.apply(alphas, *feats)
+
+
 # --------------------------------------------------------------------------
 # E1 / M: evaluation
 # --------------------------------------------------------------------------

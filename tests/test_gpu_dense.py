@@ -124,3 +124,27 @@ def test_module_routing_matches_unfused_modules():
     x3 = torch.randn(10, 48, device=DEV)
     assert not fused.can_fuse(lin3, x3)
     torch.testing.assert_close(fused.linear_act(lin3, x3, act, dr), act(lin3(x3)))
+
+
+@pytest.mark.parametrize("M,n", [(2, 1000), (3, 255404), (1, 7), (4, 64)])
+def test_modal_weighted_sum_vs_torch(M, n):
+    """out = sum_m softmax(alphas)_m F_m (out_Layer.py:52-54): forward and all gradients against
+    the reference formulation in torch (fp64 for the reductions)."""
+    g = torch.Generator().manual_seed(M * 100 + n % 97)
+    feats = [torch.randn(n, 64, generator=g) for _ in range(M)]
+    alphas = torch.randn(M, generator=g)
+    up = torch.randn(n, 64, generator=g)
+    fd = [f.to(DEV).requires_grad_(True) for f in feats]
+    ad = alphas.to(DEV).requires_grad_(True)
+    assert ops.modal_sum_supported(fd, ad)
+    out = ops.modal_sum(fd, ad)
+    out.backward(up.to(DEV))
+    fr = [f.double().requires_grad_(True) for f in feats]
+    ar = alphas.double().requires_grad_(True)
+    ref = torch.sum(torch.stack(fr, dim=0) * torch.softmax(ar, dim=0).unsqueeze(-1).unsqueeze(-1), dim=0)
+    ref.backward(up.double())
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    for a, b in zip(fd, fr):
+        torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-5, atol=1e-6)
+    scale = float(ar.grad.abs().max()) + 1e-12
+    assert float((ad.grad.cpu().double() - ar.grad).abs().max()) <= 1e-4 * scale + 1e-6
