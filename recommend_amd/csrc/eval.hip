@@ -20,326 +20,10 @@
 // together.  Every lane sees its items in ascending id order and insertion uses a
 // strict '>', so equal scores keep the lower item id first; the merge of the
 // per-slice lists orders by (score desc, id asc) explicitly.
-#include "common.h"
+#include "topk_filter.h"
+#include "topk_kernel.h"
 
 namespace {
-
-using rk::kWave;
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-
-constexpr int TI = 32;     // items per LDS tile (MFMA rows)
-constexpr int UPW = 64;    // users per wavefront
-constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
-constexpr int QS = 8;      // queue slots per lane
-constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
-
-// list length the kernel is compiled for: K rounded up to a multiple of 4 (an insertion costs one
-// step per list entry, and a longer list also lowers the threshold that filters candidates)
-__host__ __device__ inline int kpad_for(int K) { return K <= 4 ? 4 : (K + 3) / 4 * 4; }
-
-// Item slices per user tile.  Every slice restarts its lists from nothing and pays the K*ln(n/K)
-// insertions of a streaming top-K again, so fewer slices are cheaper; what slices buy is a grid
-// that fills the chip evenly.  The estimate below is launch rounds (two workgroups fit a CU)
-// times the work per round, with 4 % of a slice's time charged per extra slice.
-inline int cu_count() {
-  static int cached = 0;
-  if (cached == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cached = n;
-  }
-  return cached;
-}
-
-inline int choose_nsplit(int n_users, int n_items) {
-  const int64_t utiles = rk::ceil_div(n_users, UPB);
-  const int64_t tiles = rk::ceil_div(n_items, TI);
-  const int64_t slots = 2 * (int64_t)cu_count();
-  int best = 1;
-  double best_cost = 0.0;
-  for (int ns = 1; ns <= 16; ++ns) {  // ns * 32 <= MERGE_MAX
-    if (ns > 1 && tiles / ns < 4) break;
-    const int64_t rounds = rk::ceil_div(utiles * ns, slots);
-    const double cost = (double)rounds / ns * (1.0 + 0.04 * ns);
-    if (ns == 1 || cost < best_cost * 0.999) {
-      best = ns;
-      best_cost = cost;
-    }
-  }
-  return best;
-}
-
-template <int KPAD>
-struct LaneList {
-  float s[KPAD];
-  int32_t id[KPAD];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int j = 0; j < KPAD; ++j) {
-      s[j] = -INFINITY;
-      id[j] = -1;
-    }
-  }
-  // Sorted insertion; a no-op for lanes whose v does not beat the last entry.  With
-  // s[j-1] >= s[j], the new s[j] is the median of (s[j-1], s[j], v): one v_med3_f32.  The ids
-  // follow the same three cases through the strict compares, so equal scores stay in arrival order.
-  __device__ __forceinline__ void insert(float v, int32_t vid) {
-    bool c_hi = v > s[KPAD - 1];
-#pragma unroll
-    for (int j = KPAD - 1; j >= 1; --j) {
-      const bool c_lo = v > s[j - 1];
-      id[j] = c_lo ? id[j - 1] : (c_hi ? vid : id[j]);
-      s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
-      c_hi = c_lo;
-    }
-    id[0] = c_hi ? vid : id[0];
-    s[0] = fmaxf(s[0], v);
-  }
-};
-
-template <int KPAD, int DC>
-__global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_topk_kernel(
-    const float *__restrict__ Uemb, int32_t n_users,
-    const float *__restrict__ Iemb, int32_t n_items,
-    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
-    int32_t nsplit, int32_t item_id_offset, float *__restrict__ part_s,
-    int32_t *__restrict__ part_id) {
-  constexpr int D = 64 * DC;
-  // two separate arrays, not one indexed by a buffer number: the compiler then knows that a DMA
-  // into one cannot alias a read of the other and does not wait for the prefetch before reading
-  __shared__ __attribute__((aligned(1024))) float tile0[4][TI * D];
-  __shared__ __attribute__((aligned(1024))) float tile1[4][TI * D];
-  // candidate queues: [wave][0] scores, [wave][1] item ids (one array, so that a score and its
-  // id, a fixed distance apart, go out in one ds_write2)
-  __shared__ uint32_t queue[4][2][QS][kWave];
-
-  const int tid = threadIdx.x;
-  const int wave = tid / kWave, lane = tid % kWave;
-  const int col = lane & 31, half = lane >> 5;
-  const int32_t split = blockIdx.x % nsplit;
-  const int32_t utile = blockIdx.x / nsplit;
-  const int32_t ubase = utile * UPB + wave * UPW;
-  const int32_t user = ubase + lane;          // the user whose list this lane keeps
-  const bool user_ok = user < n_users;
-
-  const int32_t tiles_total = (n_items + TI - 1) / TI;
-  const int32_t t_lo = (int32_t)((int64_t)tiles_total * split / nsplit);
-  const int32_t t_hi = (int32_t)((int64_t)tiles_total * (split + 1) / nsplit);
-
-  // user fragments B[k][j = col]: chain A multiplies users ubase+col, chain B users ubase+32+col;
-  // this lane holds k = 64c + 32*half + m
-  float bfa[DC][32], bfb[DC][32];
-#pragma unroll
-  for (int c = 0; c < DC; ++c)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      const int64_t off = 64 * c + 32 * half + 4 * q;
-      if (ubase + col < n_users)
-        va = *reinterpret_cast<const float4 *>(Uemb + (int64_t)(ubase + col) * D + off);
-      if (ubase + 32 + col < n_users)
-        vb = *reinterpret_cast<const float4 *>(Uemb + (int64_t)(ubase + 32 + col) * D + off);
-      bfa[c][4 * q + 0] = va.x; bfa[c][4 * q + 1] = va.y; bfa[c][4 * q + 2] = va.z; bfa[c][4 * q + 3] = va.w;
-      bfb[c][4 * q + 0] = vb.x; bfb[c][4 * q + 1] = vb.y; bfb[c][4 * q + 2] = vb.z; bfb[c][4 * q + 3] = vb.w;
-    }
-
-  // train-mask cursor of this lane's user (item ids ascending)
-  int32_t mcur = 0, mend = 0;
-  if (mask_ptr && user_ok) {
-    mcur = mask_ptr[user];
-    mend = mask_ptr[user + 1];
-    int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
-    const int32_t first = t_lo * TI;
-    while (lo < hi) {
-      const int32_t mid = (lo + hi) >> 1;
-      if (mask_items[mid] < first)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    mcur = lo;
-  }
-  int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
-
-  LaneList<KPAD> list;
-  list.init();
-  float thr = -INFINITY;
-  int qc = 0;
-
-  // Tile staging by LDS-DMA: one wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly from
-  // per-lane global addresses; slot s of row r holds chunk s ^ (r & 15) of that item's embedding.
-  constexpr int CPR = D / 4;     // 16-byte chunks per row
-  constexpr int RPP = 64 / CPR;  // rows per 1-KiB piece
-  constexpr int PIECES = TI / RPP;
-  // A full tile is one contiguous block of the table: the per-lane byte offset of piece p is a
-  // loop-invariant pattern XOR a per-piece constant (rows p*RPP + l with l < RPP never carry into
-  // the bits that p*RPP sets), so a piece costs one XOR besides the DMA instruction itself.
-  const int l_row = lane / CPR, l_slot = lane % CPR;
-  uint32_t lane_off = (uint32_t)(l_row * D * 4 + (((l_slot & ~15) | ((l_slot & 15) ^ l_row)) * 16));
-  auto issue_tile = [&](int32_t t, float *dst) {
-    asm volatile("" : "+v"(lane_off));  // keep the per-piece offsets from being hoisted into registers
-    if ((t + 1) * TI <= n_items) {
-      const char *tile_base = reinterpret_cast<const char *>(Iemb + (int64_t)t * TI * D);
-#pragma unroll
-      for (int p = 0; p < PIECES; ++p) {
-        const uint32_t off = (lane_off ^ (uint32_t)(((p * RPP) & 15) * 16)) + (uint32_t)(p * 1024);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(tile_base + off),
-            (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
-      }
-      return;
-    }
-    // the last, partial tile: rows past the end of the table re-read the last item (their scores
-    // are discarded after the multiplication); same offset pattern, row clamped per lane
-#pragma unroll
-    for (int p = 0; p < PIECES; ++p) {
-      const uint32_t off = lane_off ^ (uint32_t)(((p * RPP) & 15) * 16);
-      const int32_t item = min(t * TI + p * RPP + (int32_t)(off / (D * 4)), n_items - 1);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void *)(
-              reinterpret_cast<const char *>(Iemb + (int64_t)item * D) + (off & (D * 4 - 1))),
-          (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
-    }
-  };
-  auto flush = [&]() {
-#pragma unroll 1
-    for (int q = 0; q < QS; ++q) {
-      const bool has = q < qc;
-      if (!__any(has)) break;
-      const float v = has ? __uint_as_float(queue[wave][0][q][lane]) : -INFINITY;
-      const int32_t vid = (int32_t)queue[wave][1][q][lane];
-      list.insert(v, vid);
-    }
-    qc = 0;
-    thr = list.s[KPAD - 1];
-  };
-  // Four scores of this lane's user (ascending item ids).  Late in the stream hardly any score
-  // beats its lane's threshold, so the wavefront first asks whether any lane has a candidate at
-  // all; only then are the four scores parked, branch free: the store always happens and the
-  // slot advances only for a candidate.
-  auto consider4 = [&](float v0, float v1, float v2, float v3, int32_t id0) {
-    const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-    if (!__any(m > thr)) return;
-    const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      queue[wave][0][qc][lane] = __float_as_uint(v[i]);
-      queue[wave][1][qc][lane] = (uint32_t)(id0 + i);
-      qc += v[i] > thr ? 1 : 0;
-    }
-    // a queue holds QS entries: insert when some lane could overflow within the next 4 scores
-    if (__any(qc > QS - 4)) flush();
-  };
-
-  uint32_t frag_off = (uint32_t)(col * D * 4 + ((8 * half) ^ (col & 15)) * 16);
-  // one tile: prefetch the next one into `nxt`, score and select from `cur`
-  auto process_tile = [&](int32_t t, const float *cur, float *nxt) {
-    if (t + 1 < t_hi) issue_tile(t + 1, nxt);   // lands during this tile's MFMA + selection
-    asm volatile("" : "+v"(frag_off));  // as for lane_off: eight hoisted addresses cost eight registers
-
-    floatx16 acc_a, acc_b;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc_a[r] = 0.0f;
-      acc_b[r] = 0.0f;
-    }
-#pragma unroll
-    for (int c = 0; c < DC; ++c) {
-      float afrag[32];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        // slot 16c + ((8*half + q) ^ (col & 15)) of row col; q < 8 only touches bits the other
-        // terms leave alone, so the eight addresses are one per-lane value XOR q*16
-        const float4 v = *reinterpret_cast<const float4 *>(
-            reinterpret_cast<const char *>(cur) + ((frag_off ^ (uint32_t)(q * 16)) + (uint32_t)(c * 256)));
-        afrag[4 * q + 0] = v.x;
-        afrag[4 * q + 1] = v.y;
-        afrag[4 * q + 2] = v.z;
-        afrag[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfa[c][m], acc_a, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfb[c][m], acc_b, 0, 0, 0);
-      }
-    }
-
-    // Lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in acc_b.
-    // After the swap every lane holds, for ITS user (ubase + lane), rows (r&3)+8*(r>>2) in lo[r]
-    // and rows 4+(r&3)+8*(r>>2) in hi[r].
-    // The swap is written as inline assembly: the compiler's builtin returns its first result for
-    // both halves.  The s_nop pair covers the 18 wait states between the last MFMA pass and a
-    // VALU read of its result, which the compiler does not insert in front of inline assembly.
-    // (the accumulators are operands of the s_nop statement so that it stays behind the MFMAs)
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a), "+v"(acc_b));
-    float lo[16], hi[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      lo[r] = acc_a[r];
-      hi[r] = acc_b[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
-
-    const int32_t item0 = t * TI;
-    // rows past the end of the item table never rank
-    if (item0 + TI > n_items) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (item0 + (r & 3) + 8 * (r >> 2) >= n_items) lo[r] = -INFINITY;
-        if (item0 + 4 + (r & 3) + 8 * (r >> 2) >= n_items) hi[r] = -INFINITY;
-      }
-    }
-    // training interactions of this user inside the tile get the mask score
-    if (__any(next_m < item0 + TI)) {
-      uint32_t mbits = 0;
-      while (next_m < item0 + TI) {
-        mbits |= 1u << (next_m - item0);
-        ++mcur;
-        next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // sign-extended bit (0 or all ones) selects between the score and the mask score
-        const uint32_t ml = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, (r & 3) + 8 * (r >> 2), 1);
-        const uint32_t mh = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, 4 + (r & 3) + 8 * (r >> 2), 1);
-        lo[r] = __uint_as_float((ml & __float_as_uint(kMasked)) | (~ml & __float_as_uint(lo[r])));
-        hi[r] = __uint_as_float((mh & __float_as_uint(kMasked)) | (~mh & __float_as_uint(hi[r])));
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      consider4(lo[4 * g], lo[4 * g + 1], lo[4 * g + 2], lo[4 * g + 3], item0 + 8 * g);
-      consider4(hi[4 * g], hi[4 * g + 1], hi[4 * g + 2], hi[4 * g + 3], item0 + 8 * g + 4);
-    }
-
-    // The DMA of the next tile must have landed before this wavefront reads it.  The wait is the
-    // builtin (vmcnt(0), other counters untouched), not inline assembly: the compiler's own
-    // wait-count bookkeeping sees it and does not add a second, earlier wait in the next tile.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-  };
-
-  if (t_lo < t_hi) issue_tile(t_lo, tile0[wave]);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  for (int32_t t = t_lo; t < t_hi; t += 2) {
-    process_tile(t, tile0[wave], tile1[wave]);
-    if (t + 1 < t_hi) process_tile(t + 1, tile1[wave], tile0[wave]);
-  }
-  flush();
-
-  if (user_ok) {
-    const int64_t base = ((int64_t)user * nsplit + split) * KPAD;
-#pragma unroll
-    for (int j = 0; j < KPAD; ++j) {
-      part_s[base + j] = list.s[j];
-      part_id[base + j] = list.id[j] < 0 ? -1 : list.id[j] + item_id_offset;
-    }
-  }
-}
 
 // Top-K of the rows of a score matrix that already exists (evaluate_all_at_k called with
 // precomputed scores).  32 lanes per row, lane j scans columns j, j+32, ... (coalesced 128-B
@@ -382,16 +66,25 @@ __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, in
 
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
-    int32_t n_users, int32_t n, int32_t K, float *__restrict__ out_s,
-    int32_t *__restrict__ out_id) {
+    int32_t n_users, int32_t n, int32_t K, const int32_t *__restrict__ skip,
+    const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
+    float *__restrict__ out_s, int32_t *__restrict__ out_id) {
   __shared__ float cs[4][MERGE_MAX];
   __shared__ int32_t ci[4][MERGE_MAX];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int32_t user = blockIdx.x * 4 + wave;
-  if (user >= n_users) return;  // wave-uniform; no block barrier below
+  const int32_t pos = blockIdx.x * 4 + wave;   // row of scores / ids
+  // user_list / user_count / gate_cap as for score_topk_kernel
+  if (user_count != nullptr) {
+    const int32_t cnt = user_count[0];
+    if (user_list == nullptr ? cnt <= gate_cap : cnt > gate_cap) return;
+    if (user_list != nullptr) n_users = min(n_users, cnt);
+  }
+  if (pos >= n_users) return;  // wave-uniform; no block barrier below
+  const int32_t user = user_list != nullptr ? user_list[pos] : pos;   // row of out
+  if (skip != nullptr && skip[user] != 0) return;   // this user's rows of out are already final
   for (int c = lane; c < n; c += kWave) {
-    cs[wave][c] = scores[(int64_t)user * n + c];
-    ci[wave][c] = ids[(int64_t)user * n + c];
+    cs[wave][c] = scores[(int64_t)pos * n + c];
+    ci[wave][c] = ids[(int64_t)pos * n + c];
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
@@ -495,16 +188,19 @@ __global__ void rank_metrics_final_kernel(const double *__restrict__ part, int32
 template <int KPAD>
 int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32_t n_users,
                       const float *Iemb, int32_t n_items, const int32_t *mask_ptr,
-                      const int32_t *mask_items, int32_t nsplit, int32_t off, float *ps,
+                      const int32_t *mask_items, int32_t nsplit, int32_t off, const int32_t *skip,
+                      const int32_t *user_list, const int32_t *user_count, int32_t gate_cap, float *ps,
                       int32_t *pi) {
   switch (DC) {
     case 1:
-      score_topk_kernel<KPAD, 1><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
-                                                        mask_items, nsplit, off, ps, pi);
+      score_topk_kernel<KPAD, 1, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
+                                                               mask_items, nsplit, off, skip, user_list, user_count,
+                                                               gate_cap, ps, pi);
       break;
     case 2:
-      score_topk_kernel<KPAD, 2><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
-                                                        mask_items, nsplit, off, ps, pi);
+      score_topk_kernel<KPAD, 2, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
+                                                               mask_items, nsplit, off, skip, user_list, user_count,
+                                                               gate_cap, ps, pi);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)",
@@ -514,35 +210,93 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
   return RK_OK;
 }
 
-}  // namespace
+struct UserSel {   // which users a launch works on; see score_topk_kernel
+  const int32_t *skip = nullptr, *list = nullptr, *count = nullptr;
+  int32_t cap = 0;
+};
 
-extern "C" {
-
-size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
-  (void)D;
-  if (n_users <= 0 || n_items <= 0 || K <= 0 || K > 32) return 0;
-  const int nsplit = choose_nsplit(n_users, n_items);
-  return (size_t)n_users * nsplit * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
-}
-
-int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, int32_t P,
-                      int32_t Kin, int32_t K, float *out_scores, int32_t *out_ids, void *stream) {
-  RK_CHECK_ARG(n_users >= 0 && P > 0 && Kin > 0 && K > 0, "bad sizes");
-  if (n_users == 0) return RK_OK;
-  RK_CHECK_ARG(scores && ids && out_scores && out_ids, "null pointer");
+int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_t P, int32_t Kin,
+                int32_t K, const UserSel &sel, float *out_scores, int32_t *out_ids, hipStream_t st) {
   RK_CHECK_ARG((int64_t)P * Kin <= MERGE_MAX, "too many candidates per user (%lld > %d)",
                (long long)P * Kin, MERGE_MAX);
   RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
-  topk_merge_kernel<<<(int)rk::ceil_div(n_users, 4), 256, 0, (hipStream_t)stream>>>(
-      scores, ids, n_users, P * Kin, K, out_scores, out_ids);
+  topk_merge_kernel<<<(int)rk::ceil_div(n_users, 4), 256, 0, st>>>(scores, ids, n_users, P * Kin, K, sel.skip,
+                                                                  sel.list, sel.count, sel.cap, out_scores,
+                                                                  out_ids);
   RK_CHECK_LAUNCH("topk_merge_kernel");
   return RK_OK;
 }
 
-int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
-                      int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
-                      int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
-                      size_t ws_bytes, void *stream) {
+// exact kernel and merge for n_users users (positions, if sel names a list) over nsplit item slices
+int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items, int32_t D,
+               const int32_t *mask_ptr, const int32_t *mask_items, int32_t K, int32_t item_id_offset,
+               int nsplit, const UserSel &sel, float *out_scores, int32_t *out_ids, float *ps, hipStream_t st) {
+  const int kp = kpad_for(K);
+  int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kp);
+  const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
+  int rc;
+#define RK_EXACT_CASE(KP)                                                                                   \
+  case KP:                                                                                                  \
+    rc = launch_score_topk<KP>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, \
+                               item_id_offset, sel.skip, sel.list, sel.count, sel.cap, ps, pi);             \
+    break;
+  switch (kp) {
+    RK_EXACT_CASE(4) RK_EXACT_CASE(8) RK_EXACT_CASE(12) RK_EXACT_CASE(16) RK_EXACT_CASE(20) RK_EXACT_CASE(24)
+    RK_EXACT_CASE(28)
+    default:
+      rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit,
+                                 item_id_offset, sel.skip, sel.list, sel.count, sel.cap, ps, pi);
+      break;
+  }
+#undef RK_EXACT_CASE
+  if (rc != RK_OK) return rc;
+  return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, out_scores, out_ids, st);
+}
+
+// Users the filter could not certify are few (ties at the K-th place, degenerate embeddings).
+// Up to kOpenCap of them are listed and ranked by a launch of their own: packed 64 to a wavefront
+// and cut into many item slices, it takes a fraction of a millisecond, where the same users
+// scattered over the full grid would each hold a wavefront for a whole pass over the items.
+constexpr int kOpenCap = 1024;
+inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpenCap, rk::ceil_div(n_users, UPB) * UPB); }
+inline int open_nsplit(int32_t n_items, int32_t K) {
+  const int64_t tiles = rk::ceil_div(n_items, TI);
+  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, (int64_t)MERGE_MAX / kpad_for(K), tiles / 4}));
+}
+
+// candidate list length of the filter pass for a final K (0: no filter pass, K too large)
+inline int filter_len(int K) { return K + 4 <= 32 ? std::max(8, kpad_for(K + 4)) : 0; }
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct TopkWorkspace {
+  size_t part, usplit, isplit, unorm, imax, open_count, open_list, cand_s, cand_id, done, total;
+};
+inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
+  TopkWorkspace w{};
+  const int nsplit = choose_nsplit(n_users, n_items);
+  const int kc = filter_len(K);
+  const size_t klen = (size_t)std::max(kpad_for(K), kc);
+  size_t off = 0;
+  w.part = off;
+  off += align256(std::max((size_t)n_users * nsplit * klen,
+                           (size_t)open_positions(n_users) * open_nsplit(n_items, K) * kpad_for(K)) * 8);
+  w.usplit = off;  off += align256((size_t)n_users * D * 4);
+  w.isplit = off;  off += align256((size_t)n_items * D * 4);
+  w.unorm = off;   off += align256((size_t)n_users * 4);
+  w.imax = off;    off += 128;   // imax and open_count share one 256-byte block, zeroed together
+  w.open_count = off; off += 128;
+  w.open_list = off;  off += align256((size_t)kOpenCap * 4);
+  w.cand_s = off;  off += align256((size_t)n_users * std::max(kc, 1) * 4);
+  w.cand_id = off; off += align256((size_t)n_users * std::max(kc, 1) * 4);
+  w.done = off;    off += align256((size_t)n_users * 4);
+  w.total = off;
+  return w;
+}
+
+int check_topk_args(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items, int32_t D,
+                    const int32_t *mask_ptr, const int32_t *mask_items, int32_t K, float *out_scores,
+                    int32_t *out_ids, void *ws, size_t ws_bytes) {
   RK_CHECK_ARG(n_users > 0 && n_items > 0, "empty score matrix");
   // evalue/metric.py:9-10
   RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
@@ -550,27 +304,91 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
   RK_CHECK_ARG(D > 0 && D % 64 == 0, "embedding width must be a multiple of 64");
   RK_CHECK_ARG(Uemb && Iemb && out_scores && out_ids && ws, "null pointer");
   RK_CHECK_ARG((mask_ptr == nullptr) == (mask_items == nullptr), "mask_ptr and mask_items go together");
-  RK_CHECK_ARG(rk::aligned16(Uemb) && rk::aligned16(Iemb), "embeddings must be 16-byte aligned");
-  RK_CHECK_ARG(ws_bytes >= rk_score_topk_ws_bytes(n_users, n_items, D, K), "workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int nsplit = choose_nsplit(n_users, n_items);
-  const int kp = kpad_for(K);
-  const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
-  float *ps = (float *)ws;
-  int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kp);
-  int rc;
-  switch (kp) {
-    case 4: rc = launch_score_topk<4>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 8: rc = launch_score_topk<8>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 12: rc = launch_score_topk<12>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 16: rc = launch_score_topk<16>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 20: rc = launch_score_topk<20>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 24: rc = launch_score_topk<24>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    case 28: rc = launch_score_topk<28>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-    default: rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit, item_id_offset, ps, pi); break;
-  }
+  RK_CHECK_ARG(rk::aligned16(Uemb) && rk::aligned16(Iemb) && rk::aligned16(ws),
+               "embeddings and workspace must be 16-byte aligned");
+  RK_CHECK_ARG(ws_bytes >= topk_workspace(n_users, n_items, D, K).total, "workspace too small");
+  return RK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
+  if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > 32) return 0;
+  return topk_workspace(n_users, n_items, D, K).total;
+}
+
+int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, int32_t P,
+                      int32_t Kin, int32_t K, float *out_scores, int32_t *out_ids, void *stream) {
+  RK_CHECK_ARG(n_users >= 0 && P > 0 && Kin > 0 && K > 0, "bad sizes");
+  if (n_users == 0) return RK_OK;
+  RK_CHECK_ARG(scores && ids && out_scores && out_ids, "null pointer");
+  return merge_lists(scores, ids, n_users, P, Kin, K, UserSel{}, out_scores, out_ids, (hipStream_t)stream);
+}
+
+int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
+                            int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
+                            int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
+                            size_t ws_bytes, void *stream) {
+  const int rc = check_topk_args(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, out_scores,
+                                 out_ids, ws, ws_bytes);
   if (rc != RK_OK) return rc;
-  return rk_topk_merge_f32(ps, pi, n_users, nsplit, kp, K, out_scores, out_ids, stream);
+  const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
+  return exact_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
+                    choose_nsplit(n_users, n_items), UserSel{}, out_scores, out_ids,
+                    (float *)((char *)ws + w.part), (hipStream_t)stream);
+}
+
+int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
+                      int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
+                      int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
+                      size_t ws_bytes, void *stream) {
+  const int kc = filter_len(K);
+  if (kc == 0 || (D != 64 && D != 128))
+    return rk_score_topk_exact_f32(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
+                                   out_scores, out_ids, ws, ws_bytes, stream);
+  int rc = check_topk_args(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, out_scores, out_ids, ws,
+                           ws_bytes);
+  if (rc != RK_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
+  char *base = (char *)ws;
+  const int nsplit = choose_nsplit(n_users, n_items);
+  float *usplit = (float *)(base + w.usplit), *isplit = (float *)(base + w.isplit);
+  float *unorm = (float *)(base + w.unorm), *imax = (float *)(base + w.imax);
+  float *cand_s = (float *)(base + w.cand_s);
+  int32_t *cand_id = (int32_t *)(base + w.cand_id), *done = (int32_t *)(base + w.done);
+  int32_t *open_count = (int32_t *)(base + w.open_count), *open_list = (int32_t *)(base + w.open_list);
+
+  // 1. split the embeddings into bf16 pairs; user norms and the largest item norm for the bound
+  RK_CHECK_HIP(hipMemsetAsync(imax, 0, 256, st));   // imax and open_count
+  if ((rc = rk::split_rows(Uemb, n_users, D, usplit, unorm, nullptr, st)) != RK_OK) return rc;
+  if ((rc = rk::split_rows(Iemb, n_items, D, isplit, nullptr, imax, st)) != RK_OK) return rc;
+  // 2. the kc best filter scores per user (local item ids)
+  float *ps = (float *)(base + w.part);
+  int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kc);
+  const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
+  if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, usplit, n_users, isplit, n_items, mask_ptr, mask_items,
+                                   nsplit, ps, pi)) != RK_OK)
+    return rc;
+  if ((rc = merge_lists(ps, pi, n_users, nsplit, kc, std::min(kc, n_items), UserSel{}, cand_s, cand_id, st)) != RK_OK)
+    return rc;
+  // 3. exact scores of the candidates, final order, certification
+  if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, std::min(kc, n_items), K, unorm,
+                                  imax, item_id_offset, out_scores, out_ids, done, open_count, open_list,
+                                  kOpenCap, st)) != RK_OK)
+    return rc;
+  // 4. the exact kernel for the users that could not be certified: the listed ones as a compact
+  //    launch; if the list overflowed (then that launch does nothing), everybody whose flag is 0
+  UserSel listed, flagged;
+  listed.list = open_list; listed.count = open_count; listed.cap = kOpenCap;
+  flagged.skip = done; flagged.count = open_count; flagged.cap = kOpenCap;
+  if ((rc = exact_topk(Uemb, open_positions(n_users), Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
+                       open_nsplit(n_items, K), listed, out_scores, out_ids, ps, st)) != RK_OK)
+    return rc;
+  return exact_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset, nsplit, flagged,
+                    out_scores, out_ids, ps, st);
 }
 
 size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K) {

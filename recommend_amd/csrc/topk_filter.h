@@ -1,0 +1,31 @@
+// Internal interface between eval.hip (exact kernels, entry points) and eval_filter.hip (the
+// bf16 x 2 candidate filter and the exact re-scoring of its candidates).
+#pragma once
+#include "common.h"
+
+namespace rk {
+
+// X[n_rows][D] fp32 -> rows of the same byte size [D bf16 high parts | D bf16 remainders];
+// norms (may be NULL): per-row Euclidean norm; max_norm (may be NULL, zeroed by the caller): the
+// largest row norm.
+int split_rows(const float *X, int64_t n_rows, int D, float *split, float *norms, float *max_norm,
+               hipStream_t st);
+
+// The fused top-K kernel on split rows: per user and item slice the kc best FILTER scores,
+// item ids local to this table.
+int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Usplit, int32_t n_users,
+                       const float *Isplit, int32_t n_items, const int32_t *mask_ptr,
+                       const int32_t *mask_items, int32_t nsplit, float *part_s, int32_t *part_id);
+
+// Exact fp32 scores of each user's kc candidates, the best K of them by (score desc, id asc)
+// written to out (ids + item_id_offset), and done[user] = 1 iff no item outside the candidates
+// can rank among those K (the smallest filter score among the candidates plus the filter's error
+// bound is below the K-th exact score, or every item is a candidate).  The other users are counted
+// in open_count[0] (zeroed by the caller) and the first open_cap of them listed in open_list.
+int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
+                      const float *cand_s, const int32_t *cand_id, int kc, int K, const float *unorm,
+                      const float *imax, int32_t item_id_offset, float *out_s, int32_t *out_id,
+                      int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
+                      hipStream_t st);
+
+}  // namespace rk

@@ -1,0 +1,567 @@
+// Shared by eval.hip (exact fp32 scores) and eval_filter.hip (bf16 x 2 filter scores): the fused
+// score + mask + top-K kernel.  See eval.hip for the description of the kernel.
+#pragma once
+#include "common.h"
+
+namespace {
+
+using rk::kWave;
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TI = 32;     // items per LDS tile (MFMA rows)
+constexpr int UPW = 64;    // users per wavefront
+constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
+constexpr int QS = 8;      // queue slots per lane
+constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
+
+// list length the kernel is compiled for: K rounded up to a multiple of 4 (an insertion costs one
+// step per list entry, and a longer list also lowers the threshold that filters candidates)
+__host__ __device__ inline int kpad_for(int K) { return K <= 4 ? 4 : (K + 3) / 4 * 4; }
+
+// Item slices per user tile.  Every slice restarts its lists from nothing and pays the K*ln(n/K)
+// insertions of a streaming top-K again, so fewer slices are cheaper; what slices buy is a grid
+// that fills the chip evenly.  The estimate below is launch rounds (two workgroups fit a CU)
+// times the work per round, with 4 % of a slice's time charged per extra slice.
+inline int cu_count() {
+  static int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
+inline int choose_nsplit(int n_users, int n_items) {
+  const int64_t utiles = rk::ceil_div(n_users, UPB);
+  const int64_t tiles = rk::ceil_div(n_items, TI);
+  const int64_t slots = 2 * (int64_t)cu_count();
+  int best = 1;
+  double best_cost = 0.0;
+  for (int ns = 1; ns <= 16; ++ns) {  // ns * 32 <= MERGE_MAX
+    if (ns > 1 && tiles / ns < 4) break;
+    const int64_t rounds = rk::ceil_div(utiles * ns, slots);
+    const double cost = (double)rounds / ns * (1.0 + 0.04 * ns);
+    if (ns == 1 || cost < best_cost * 0.999) {
+      best = ns;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+template <int KPAD>
+struct LaneList {
+  float s[KPAD];
+  int32_t id[KPAD];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) {
+      s[j] = -INFINITY;
+      id[j] = -1;
+    }
+  }
+  // Sorted insertion; a no-op for lanes whose v does not beat the last entry.  With
+  // s[j-1] >= s[j], the new s[j] is the median of (s[j-1], s[j], v): one v_med3_f32.  The ids
+  // follow the same three cases through the strict compares, so equal scores stay in arrival order.
+  __device__ __forceinline__ void insert(float v, int32_t vid) {
+    bool c_hi = v > s[KPAD - 1];
+#pragma unroll
+    for (int j = KPAD - 1; j >= 1; --j) {
+      const bool c_lo = v > s[j - 1];
+      // (operands read first: a lazily evaluated ?: becomes a load through a pointer phi, which
+      // keeps part of the list in memory)
+      const int32_t above = id[j - 1], here = id[j];
+      id[j] = c_lo ? above : (c_hi ? vid : here);
+      s[j] = __builtin_amdgcn_fmed3f(s[j - 1], s[j], v);
+      c_hi = c_lo;
+    }
+    const int32_t first = id[0];
+    id[0] = c_hi ? vid : first;
+    s[0] = fmaxf(s[0], v);
+  }
+};
+
+// FILTER = false: Uemb / Iemb are the fp32 embeddings and a score is the exact fp32 fma chain.
+// FILTER = true: they point at "split" rows of the same byte size, [D bf16 high parts | D bf16
+// remainders] (x ~ h + m to 16 bits), and a score is u_h.i_h + u_h.i_m + u_m.i_h on
+// v_mfma_f32_32x32x16_bf16 -- a filter score within 2^-14 * |u| * |i| of the exact one, used to
+// pick candidates that are then re-scored exactly.  The bf16 MFMA runs on the matrix pipe, which
+// (unlike the fp32-input MFMA) the selection's vector instructions overlap with.
+// skip (may be NULL): users with a non-zero flag need no result; a wavefront whose 64 users are
+// all flagged returns at once.
+// user_list / user_count / gate_cap select which users the launch works on:
+//   user_list == NULL, user_count == NULL: users 0..n_users-1 (rows of Uemb, of the mask, of part_*).
+//   user_list == NULL, user_count != NULL: the same, but only if *user_count > gate_cap; otherwise
+//     every wavefront returns at once (the launch is the overflow path of the compacted one).
+//   user_list != NULL: position p < *user_count stands for user user_list[p] (row of Uemb and of
+//     the mask); part_* rows are positions; nothing runs if *user_count > gate_cap.  n_users is
+//     then the number of positions the grid covers.
+template <int KPAD, int DC, bool FILTER>
+__global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_topk_kernel(
+    const float *__restrict__ Uemb, int32_t n_users,
+    const float *__restrict__ Iemb, int32_t n_items,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
+    int32_t nsplit, int32_t item_id_offset, const int32_t *__restrict__ skip,
+    const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
+    float *__restrict__ part_s, int32_t *__restrict__ part_id) {
+  constexpr int D = 64 * DC;
+  // Exact scores: every wavefront streams its own copy of the item tiles through a private pair
+  // of buffers (the MFMA chain is the bound, nothing is shared, no barriers).
+  // Filter scores: fast enough to be bound by the tile stream otherwise (four private copies of
+  // the table per workgroup out of L2 / Infinity Cache, one tile of lookahead against ~1 us of
+  // latency), so the four wavefronts share a ring of two stages of RN tiles, each wavefront
+  // loading a quarter of every tile, with one workgroup barrier per stage.
+  constexpr int RN = 4;   // tiles per stage
+  __shared__ __attribute__((aligned(1024))) float tile0[FILTER ? 1 : 4][FILTER ? 1 : TI * D];
+  __shared__ __attribute__((aligned(1024))) float tile1[FILTER ? 1 : 4][FILTER ? 1 : TI * D];
+  __shared__ __attribute__((aligned(1024))) float ring[FILTER ? 2 * RN : 1][FILTER ? TI * D : 1];
+  // candidate queues: [wave][0] scores, [wave][1] item ids (one array, so that a score and its
+  // id, a fixed distance apart, go out in one ds_write2)
+  __shared__ uint32_t queue[4][2][QS][kWave];
+
+  const int tid = threadIdx.x;
+  const int wave = tid / kWave, lane = tid % kWave;
+  const int col = lane & 31, half = lane >> 5;
+  const int32_t split = blockIdx.x % nsplit;
+  const int32_t utile = blockIdx.x / nsplit;
+  const int32_t ubase = utile * UPB + wave * UPW;
+  const int32_t user = ubase + lane;          // the position whose list this lane keeps
+  // the filter's wavefronts share tiles and barriers, all of them stay; it takes neither a skip
+  // list nor a user list
+  if constexpr (!FILTER) {
+    if (user_count != nullptr) {
+      const int32_t cnt = user_count[0];
+      if (user_list == nullptr ? cnt <= gate_cap : cnt > gate_cap) return;
+      if (user_list != nullptr) n_users = min(n_users, cnt);
+    }
+    if (ubase >= n_users) return;             // wave-uniform
+  }
+  const bool user_ok = user < n_users;
+  // rows of Uemb / of the mask behind positions ubase+col, ubase+32+col and ubase+lane
+  int64_t row_a = ubase + col, row_b = ubase + 32 + col, row_l = user;
+  if constexpr (!FILTER) {
+    if (user_list != nullptr) {
+      row_a = ubase + col < n_users ? user_list[ubase + col] : 0;
+      row_b = ubase + 32 + col < n_users ? user_list[ubase + 32 + col] : 0;
+      row_l = user_ok ? user_list[user] : 0;
+    }
+    if (skip != nullptr && __all(!user_ok || skip[user_ok ? row_l : 0] != 0)) return;   // wave-uniform
+  }
+
+  const int32_t tiles_total = (n_items + TI - 1) / TI;
+  const int32_t t_lo = (int32_t)((int64_t)tiles_total * split / nsplit);
+  const int32_t t_hi = (int32_t)((int64_t)tiles_total * (split + 1) / nsplit);
+
+  // user fragments B[k][j = col]: chain A multiplies users ubase+col, chain B users ubase+32+col.
+  // fp32: this lane holds k = 64c + 32*half + m.  Split rows: 16 k per MFMA, this lane holds
+  // k = 16*kb + 8*half + 0..7 of the high parts (uh) and of the remainders (um).
+  constexpr int KB = D / 16;
+  float bfa[FILTER ? 1 : DC][FILTER ? 1 : 32], bfb[FILTER ? 1 : DC][FILTER ? 1 : 32];
+  bf16x8 uha[FILTER ? KB : 1], uma[FILTER ? KB : 1], uhb[FILTER ? KB : 1], umb[FILTER ? KB : 1];
+  if constexpr (FILTER) {
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      uint4 ha = zero, ma = zero, hb = zero, mb = zero;
+      const int64_t off = (16 * kb + 8 * half) / 2;   // in floats: 8 bf16 = 4 floats
+      if (ubase + col < n_users) {
+        const float *row = Uemb + row_a * D;
+        ha = *reinterpret_cast<const uint4 *>(row + off);
+        ma = *reinterpret_cast<const uint4 *>(row + D / 2 + off);
+      }
+      if (ubase + 32 + col < n_users) {
+        const float *row = Uemb + row_b * D;
+        hb = *reinterpret_cast<const uint4 *>(row + off);
+        mb = *reinterpret_cast<const uint4 *>(row + D / 2 + off);
+      }
+      uha[kb] = __builtin_bit_cast(bf16x8, ha);
+      uma[kb] = __builtin_bit_cast(bf16x8, ma);
+      uhb[kb] = __builtin_bit_cast(bf16x8, hb);
+      umb[kb] = __builtin_bit_cast(bf16x8, mb);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < DC; ++c)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        const int64_t off = 64 * c + 32 * half + 4 * q;
+        if (ubase + col < n_users)
+          va = *reinterpret_cast<const float4 *>(Uemb + row_a * D + off);
+        if (ubase + 32 + col < n_users)
+          vb = *reinterpret_cast<const float4 *>(Uemb + row_b * D + off);
+        bfa[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 0] = va.x; bfa[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 1] = va.y;
+        bfa[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 2] = va.z; bfa[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 3] = va.w;
+        bfb[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 0] = vb.x; bfb[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 1] = vb.y;
+        bfb[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 2] = vb.z; bfb[FILTER ? 0 : c][FILTER ? 0 : 4 * q + 3] = vb.w;
+      }
+  }
+
+  // train-mask cursor of this lane's user (item ids ascending)
+  int32_t mcur = 0, mend = 0;
+  if (mask_ptr && user_ok) {
+    mcur = mask_ptr[row_l];
+    mend = mask_ptr[row_l + 1];
+    int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
+    const int32_t first = t_lo * TI;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (mask_items[mid] < first)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    mcur = lo;
+  }
+  int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+
+  LaneList<KPAD> list;
+  list.init();
+  float thr = -INFINITY;
+  int qc = 0;
+
+  // Tile staging by LDS-DMA: one wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly from
+  // per-lane global addresses; slot s of row r holds chunk s ^ (r & 15) of that item's embedding.
+  constexpr int CPR = D / 4;     // 16-byte chunks per row
+  constexpr int RPP = 64 / CPR;  // rows per 1-KiB piece
+  constexpr int PIECES = TI / RPP;
+  // A full tile is one contiguous block of the table: the per-lane byte offset of piece p is a
+  // loop-invariant pattern XOR a per-piece constant (rows p*RPP + l with l < RPP never carry into
+  // the bits that p*RPP sets), so a piece costs one XOR besides the DMA instruction itself.
+  // Exact: a wavefront issues all pieces of its private tile.  Filter: piece range NP*wave..
+  constexpr int NP = FILTER ? PIECES / 4 : PIECES;
+  const int pbase = FILTER ? __builtin_amdgcn_readfirstlane(wave) * NP : 0;
+  const int l_row = lane / CPR, l_slot = lane % CPR;
+  uint32_t lane_off = (uint32_t)(l_row * D * 4 + (((l_slot & ~15) | ((l_slot & 15) ^ l_row)) * 16));
+  // The DMA instructions are inline assembly, and on purpose: the compiler's wait-count pass
+  // tracks LDS-DMA per LDS array and makes later reads of an array wait for "its" DMAs, but with
+  // four buffers and the loads of the mask cursor in between it falls back to vmcnt(0) in front
+  // of some tile reads, which drains the whole prefetch ring.  Written this way the pass knows
+  // nothing of the DMAs; the kernel's own s_waitcnt (and, for the shared ring, barrier) in front
+  // of every first read of a tile is the only synchronisation, and it is sufficient.  More
+  // operations in the in-order counter than the compiler knows of only make its own vmcnt(N)
+  // waits stronger.
+  auto dma_piece = [&](const char *base, uint32_t off, uint32_t lds_addr) {   // uniform base + lane offset
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 : : "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
+  };
+  auto dma_piece_lane = [&](const char *addr, uint32_t lds_addr) {            // per-lane address
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 : : "v"(addr), "s"(lds_addr) : "memory", "m0");
+  };
+  auto issue_tile = [&](int32_t t, float *dst) {
+    asm volatile("" : "+v"(lane_off));  // keep the per-piece offsets from being hoisted into registers
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)dst + (uint32_t)pbase * 1024u);
+    if ((t + 1) * TI <= n_items) {
+      const char *tile_base = reinterpret_cast<const char *>(Iemb + (int64_t)t * TI * D) + (int64_t)pbase * 1024;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int p = pbase + j;
+        const uint32_t off = (lane_off ^ (uint32_t)(((p * RPP) & 15) * 16)) + (uint32_t)(j * 1024);
+        dma_piece(tile_base, off, lds0 + (uint32_t)(j * 1024));
+      }
+      return;
+    }
+    // the last, partial tile: rows past the end of the table re-read the last item (their scores
+    // are discarded after the multiplication); same offset pattern, row clamped per lane
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int p = pbase + j;
+      const uint32_t off = lane_off ^ (uint32_t)(((p * RPP) & 15) * 16);
+      const int32_t item = min(t * TI + p * RPP + (int32_t)(off / (D * 4)), n_items - 1);
+      dma_piece_lane(reinterpret_cast<const char *>(Iemb + (int64_t)item * D) + (off & (D * 4 - 1)),
+                     lds0 + (uint32_t)(j * 1024));
+    }
+  };
+  // The queue is read and written through inline assembly.  The compiler's wait-count pass makes
+  // every LDS access that does not alias a pending LDS-DMA wait for ALL pending DMAs (vmcnt(0)),
+  // which would stall each queue access on the tile prefetch issued just before; it does not look
+  // into assembly.  LDS operations of a wavefront execute in order, so the writes need no wait;
+  // the reads carry their own.  The statements are volatile, which keeps them in program order
+  // among themselves, and deliberately without a "memory" clobber: with one, the optimiser must
+  // assume they modify the lists behind the lambdas' references and leaves part of a list in
+  // memory.
+  const uint32_t qbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&queue[wave][0][0][lane];
+  constexpr int kIdPlane = QS * kWave * 4;   // bytes from a score to its id
+  static_assert(kIdPlane == 8 * 256, "ds_write2st64 offset1");
+  auto flush = [&]() {
+    // Bottom-tested with a single exit (an empty first round inserts -inf, a no-op): any other
+    // shape makes the loop carry part of the list in two sets of registers, with a copy per entry
+    // and round.
+    int q = 0;
+#pragma unroll 1
+    do {
+      const bool has = q < qc;
+      uint32_t qs, qid;
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(qs), "=&v"(qid) : "v"(qbase + (uint32_t)q * 256u));
+      list.insert(has ? __uint_as_float(qs) : -INFINITY, (int32_t)qid);
+      ++q;
+    } while (__any(q < qc));
+    qc = 0;
+    thr = list.s[KPAD - 1];
+  };
+  // Four scores of this lane's user (ascending item ids).  Late in the stream hardly any score
+  // beats its lane's threshold, so the wavefront first asks whether any lane has a candidate at
+  // all; only then are the four scores parked, branch free: the store always happens and the
+  // slot advances only for a candidate.
+  auto consider4 = [&](float v0, float v1, float v2, float v3, int32_t id0) {
+    // (v_max3 written out: fmaxf() on values that come out of inline assembly costs a
+    // canonicalising v_max per operand; a NaN operand is ignored either way)
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v0), "v"(v1), "v"(v2));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v3));
+#ifdef RK_EXP_NOSEL
+    list.s[0] = fmaxf(list.s[0], m); return;
+#endif
+    if (!__any(m > thr)) return;
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:8"
+                   : : "v"(qbase + (uint32_t)qc * 256u), "v"(v[i]), "v"(id0 + i));
+      qc += v[i] > thr ? 1 : 0;
+    }
+    // a queue holds QS entries: insert when some lane could overflow within the next 4 scores
+    if (__any(qc > QS - 4)) flush();
+  };
+
+  // fp32 rows: slot 16c + ((8*half + q) ^ (col & 15)) of row col; q < 8 only touches bits the other
+  // terms leave alone, so the eight addresses are one per-lane value XOR q*16.  Split rows: the
+  // 16-byte chunk of k-block kb is 2*kb + half in the high-part plane (the remainder plane follows
+  // D*2 bytes later); again the lane part (half) and the static part (2*kb) use different bits.
+  uint32_t frag_off = FILTER ? (uint32_t)(col * D * 4 + (half ^ (col & 15)) * 16)
+                             : (uint32_t)(col * D * 4 + ((8 * half) ^ (col & 15)) * 16);
+  // Lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in acc_b.
+  // After the swap every lane holds, for ITS user (ubase + lane), rows (r&3)+8*(r>>2) in lo[r]
+  // and rows 4+(r&3)+8*(r>>2) in hi[r].
+  // The swap is written as inline assembly: the compiler's builtin returns its first result for
+  // both halves.  The s_nop pair covers the 18 wait states between the last MFMA pass and a
+  // VALU read of its result, which the compiler does not insert in front of inline assembly.
+  // (the accumulators are operands of the s_nop statement so that it stays behind the MFMAs)
+  auto swap_halves = [&](floatx16 &acc_a, floatx16 &acc_b, float (&lo)[16], float (&hi)[16]) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a), "+v"(acc_b));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      lo[r] = acc_a[r];
+      hi[r] = acc_b[r];
+    }
+#ifndef RK_EXP_NOSWAP
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
+#endif
+  };
+  // scores of tile t that do not rank as computed: rows past the end of the item table (never),
+  // training interactions of this lane's user (the mask score)
+  auto range_and_mask = [&](int32_t t, float (&lo)[16], float (&hi)[16]) {
+    const int32_t item0 = t * TI;
+    if (item0 + TI > n_items) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (item0 + (r & 3) + 8 * (r >> 2) >= n_items) lo[r] = -INFINITY;
+        if (item0 + 4 + (r & 3) + 8 * (r >> 2) >= n_items) hi[r] = -INFINITY;
+      }
+    }
+    if (__any(next_m < item0 + TI)) {
+      uint32_t mbits = 0;
+      while (next_m < item0 + TI) {
+        mbits |= 1u << (next_m - item0);
+        ++mcur;
+        next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // sign-extended bit (0 or all ones) selects between the score and the mask score
+        const uint32_t ml = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, (r & 3) + 8 * (r >> 2), 1);
+        const uint32_t mh = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, 4 + (r & 3) + 8 * (r >> 2), 1);
+        lo[r] = __uint_as_float((ml & __float_as_uint(kMasked)) | (~ml & __float_as_uint(lo[r])));
+        hi[r] = __uint_as_float((mh & __float_as_uint(kMasked)) | (~mh & __float_as_uint(hi[r])));
+      }
+    }
+  };
+  // the g-th eight scores of a tile (g < 4): rows 8g..8g+3 are lo[4g..], rows 8g+4..8g+7 hi[4g..]
+  auto consider_lo = [&](int32_t t, int g, const float (&lo)[16]) {
+    consider4(lo[4 * g], lo[4 * g + 1], lo[4 * g + 2], lo[4 * g + 3], t * TI + 8 * g);
+  };
+  auto consider_hi = [&](int32_t t, int g, const float (&hi)[16]) {
+    consider4(hi[4 * g], hi[4 * g + 1], hi[4 * g + 2], hi[4 * g + 3], t * TI + 8 * g + 4);
+  };
+
+  if constexpr (FILTER) {
+    // The filter's multiplications run on the matrix pipe next to the vector instructions of the
+    // selection, so the loop is software-pipelined inside the wavefront: while the scores of tile
+    // t (already in lo/hi) are selected, the MFMAs of tile t+1 are issued in 8 parts, one in
+    // front of each group of four scores.
+    //
+    // The tiles come through a ring of two stages of RN tiles.  Before the first tile of stage s
+    // is multiplied every wavefront waits for its own quarters of that stage (issued a whole
+    // stage earlier) and meets the others at the barrier; the barrier also says that everybody
+    // has multiplied the tiles of stage s-1, whose buffers the quarters of stage s+1 then
+    // overwrite.  One barrier per RN tiles rather than per tile: the wavefronts' tile times
+    // differ a lot (a list insertion now and then), and every barrier costs the slowest one's.
+    // Past the end of the slice the last tile is loaded (and multiplied) again; those copies and
+    // products are never used.
+    constexpr int kVmPerStage = RN * NP;
+    static_assert(kVmPerStage < 64, "vmcnt immediate");
+    constexpr int kWaitStage = 0x0F70 | (kVmPerStage & 15) | ((kVmPerStage >> 4) << 14);   // vmcnt(RN*NP)
+    constexpr int PARTS = 2 * KB;                  // 3 MFMAs each
+    constexpr int PPG = PARTS / 8;                 // parts per group of four scores
+    floatx16 acc_a, acc_b;
+    // item fragments of k-block kb live in fh/fm[kb & 1] and are read one k-block (two groups of
+    // scores) ahead of their MFMAs, so that the LDS latency is not waited for
+    bf16x8 fh[2], fm[2];
+    auto load_frags = [&](int kb, const float *src) {
+      // chunk 2*kb + half of the high-part plane, swizzled in its low 4 bits.  The remainder
+      // plane lies D*2 bytes further: at D = 64 that is bit 3 of the (swizzled) chunk index, so
+      // the offset is applied by XOR; at D = 128 it is outside the swizzled bits
+      const uint32_t a_h = frag_off ^ (uint32_t)((2 * kb) * 16);
+      const uint32_t a_m = DC == 1 ? (a_h ^ 128u) : (a_h + 256u);
+      fh[kb & 1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a_h));
+      fm[kb & 1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a_m));
+    };
+    auto mfma_part = [&](int part, const float *src) {
+      const int kb = part >> 1, b = kb & 1;
+      if ((part & 1) == 0) {
+        if (part == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc_a[r] = 0.0f;
+            acc_b[r] = 0.0f;
+          }
+        }
+        if (kb + 1 < KB) load_frags(kb + 1, src);
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm[b], uha[FILTER ? kb : 0], acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm[b], uhb[FILTER ? kb : 0], acc_b, 0, 0, 0);
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uma[FILTER ? kb : 0], acc_a, 0, 0, 0);
+      } else {
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], umb[FILTER ? kb : 0], acc_b, 0, 0, 0);
+        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uha[FILTER ? kb : 0], acc_a, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uhb[FILTER ? kb : 0], acc_b, 0, 0, 0);
+      }
+    };
+    float lo[16], hi[16];
+    auto issue_stage = [&](int32_t first, int half_idx) {
+#pragma unroll
+      for (int j = 0; j < RN; ++j) issue_tile(min(first + j, t_hi - 1), ring[half_idx * RN + j]);
+    };
+    // select tile t (scores in lo/hi) while tile t+1 (in nxt, k-block 0 already read) is multiplied
+    auto body = [&](int32_t t, const float *nxt) {
+      range_and_mask(t, lo, hi);
+      asm volatile("" : "+v"(frag_off));  // as for lane_off: hoisted addresses cost registers
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) mfma_part((2 * g) * PPG + j, nxt);
+        consider_lo(t, g, lo);
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) mfma_part((2 * g + 1) * PPG + j, nxt);
+        consider_hi(t, g, hi);
+      }
+    };
+    // The user fragments and the mask cursor are global loads too: all of them have to be back
+    // before the in-order counter is used to tell the stages apart.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    static_assert(RN >= 2, "the stage of tile t+2 is synchronised at the end of tile t");
+    if (t_lo < t_hi) {
+      issue_stage(t_lo, 0);
+      issue_stage(t_lo + RN, 1);
+      __builtin_amdgcn_s_waitcnt(kWaitStage);      // stage 0 is in
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      load_frags(0, ring[0]);
+#pragma unroll
+      for (int part = 0; part < PARTS; ++part) mfma_part(part, ring[0]);
+      load_frags(0, ring[1]);
+      swap_halves(acc_a, acc_b, lo, hi);
+    }
+    int half_idx = 0;
+    for (int32_t tb = t_lo; tb < t_hi; tb += RN, half_idx ^= 1) {
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        const int32_t t = tb + j;
+        if (t >= t_hi) break;                      // uniform over the workgroup
+        body(t, j == RN - 1 ? ring[(half_idx ^ 1) * RN] : ring[half_idx * RN + j + 1]);
+        if (j == RN - 2) {                         // tile t+2 opens the next stage
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifndef RK_EXP_NOBAR
+          __builtin_amdgcn_s_barrier();
+#endif
+          asm volatile("" ::: "memory");
+#ifndef RK_EXP_NODMA
+          issue_stage(tb + 2 * RN, half_idx);
+#endif
+        }
+        load_frags(0, j + 2 < RN ? ring[half_idx * RN + j + 2] : ring[(half_idx ^ 1) * RN + j + 2 - RN]);
+        swap_halves(acc_a, acc_b, lo, hi);         // scores of tile t+1
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  } else {
+    // one tile: score and select from `cur`, the next tile on its way into `nxt`
+    auto process_tile = [&](int32_t t, const float *cur, float *nxt) {
+      if (t + 1 < t_hi) issue_tile(t + 1, nxt);   // lands during this tile's MFMA + selection
+      asm volatile("" : "+v"(frag_off));  // as for lane_off: eight hoisted addresses cost eight registers
+      floatx16 acc_a, acc_b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_a[r] = 0.0f;
+        acc_b[r] = 0.0f;
+      }
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        float afrag[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 v = *reinterpret_cast<const float4 *>(
+              reinterpret_cast<const char *>(cur) + ((frag_off ^ (uint32_t)(q * 16)) + (uint32_t)(c * 256)));
+          afrag[4 * q + 0] = v.x;
+          afrag[4 * q + 1] = v.y;
+          afrag[4 * q + 2] = v.z;
+          afrag[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+          acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfa[FILTER ? 0 : c][FILTER ? 0 : m], acc_a, 0, 0, 0);
+          acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[m], bfb[FILTER ? 0 : c][FILTER ? 0 : m], acc_b, 0, 0, 0);
+        }
+      }
+      float lo[16], hi[16];
+      swap_halves(acc_a, acc_b, lo, hi);
+      range_and_mask(t, lo, hi);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        consider_lo(t, g, lo);
+        consider_hi(t, g, hi);
+      }
+      // The DMA of the next tile must have landed before this wavefront reads it.  The wait is
+      // the builtin (vmcnt(0), other counters untouched), not inline assembly: the compiler's own
+      // wait-count bookkeeping sees it and does not add a second, earlier wait in the next tile.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
+    if (t_lo < t_hi) issue_tile(t_lo, tile0[wave]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int32_t t = t_lo; t < t_hi; t += 2) {
+      process_tile(t, tile0[wave], tile1[wave]);
+      if (t + 1 < t_hi) process_tile(t + 1, tile1[wave], tile0[wave]);
+    }
+  }
+  flush();
+
+  if (user_ok) {
+    const int64_t base = ((int64_t)user * nsplit + split) * KPAD;
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) {
+      part_s[base + j] = list.s[j];
+      part_id[base + j] = list.id[j] < 0 ? -1 : list.id[j] + item_id_offset;
+    }
+  }
+}
+
+}  // namespace

@@ -76,7 +76,8 @@ def test_verifier_and_tester_vs_reference(golden, name):
 
 
 @pytest.mark.parametrize("U,I,D,K", [(1, 1, 64, 1), (5, 7, 64, 7), (129, 33, 64, 20), (300, 1000, 128, 32),
-                                      (257, 4099, 64, 20), (1000, 257, 64, 5), (64, 20000, 64, 10)])
+                                      (257, 4099, 64, 20), (1000, 257, 64, 5), (64, 20000, 64, 10),
+                                      (2500, 400, 64, 20), (1500, 3000, 128, 10)])
 def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K):
     """Quantised embeddings give many exactly equal scores: ids must come out in
     (score desc, id asc) order, identical to the oracle, for awkward shapes."""
@@ -98,6 +99,56 @@ def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K):
     o_s2, o_i2 = eval_oracle.score_topk(ue, ie, K)
     np.testing.assert_array_equal(ids2.cpu().numpy(), o_i2)
     np.testing.assert_array_equal(s2.cpu().numpy(), o_s2)
+
+
+@pytest.mark.parametrize("U,I,D,K,scale", [(3000, 9001, 64, 20, 0.1), (700, 5000, 128, 10, 1.0),
+                                            (520, 2000, 64, 28, 30.0), (300, 2000, 64, 32, 0.1),
+                                            (1300, 700, 128, 5, 0.1)])
+def test_filtered_ranking_equals_exact_kernel(U, I, D, K, scale):
+    """rk_score_topk_f32 (bf16 candidate filter, exact re-scoring, exact kernel for whoever is
+    left) returns the bits of rk_score_topk_exact_f32; K > 28 and widths other than 64/128 take
+    the exact kernel directly."""
+    g = torch.Generator().manual_seed(U + I)
+    ue = (torch.randn(U, D, generator=g) * scale).to(DEV)
+    ie = (torch.randn(I, D, generator=g) * scale).to(DEV)
+    ie[::7] *= 4.0          # a wide spread of item norms loosens the filter's error bound
+    rng = np.random.default_rng(I)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 20 * U), rng.integers(0, I, 20 * U), U)
+    for off in (0, 12345):
+        fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off)
+        es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off, exact_only=True)
+        assert torch.equal(fi, ei)
+        assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+    o_s, o_i = eval_oracle.score_topk(ue[:64].cpu().numpy(), ie.cpu().numpy(), K, ptr[:65], mcols[:ptr[64]])
+    np.testing.assert_array_equal(fi[:64].cpu().numpy() - 12345, o_i)
+    np.testing.assert_array_equal(fs[:64].cpu().numpy(), o_s)
+
+
+@pytest.mark.parametrize("U", [300, 1500])
+def test_filter_falls_back_when_nothing_can_be_certified(U):
+    """All-zero users tie every item (nobody certified: few users go through the compacted exact
+    launch, more than its 1024 slots through the flagged full-grid one); non-finite embeddings
+    make the error bound useless.  Either way the exact kernel's answer comes out."""
+    I, D, K = 900, 64, 20
+    g = torch.Generator().manual_seed(U)
+    ie = torch.randn(I, D, generator=g).to(DEV)
+    ue = torch.zeros(U, D, device=DEV)
+    ue[::3] = torch.randn(U, D, generator=g).to(DEV)[::3]
+    rng = np.random.default_rng(U)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 5 * U), rng.integers(0, I, 5 * U), U)
+    fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols))
+    es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), exact_only=True)
+    assert torch.equal(fi, ei) and torch.equal(fs, es)
+    o_s, o_i = eval_oracle.score_topk(ue.cpu().numpy(), ie.cpu().numpy(), K, ptr, mcols)
+    np.testing.assert_array_equal(fi.cpu().numpy(), o_i)
+    ie2 = ie.clone()
+    ie2[5, 3] = float("inf")
+    ie2[17, 0] = float("nan")
+    ie2[40] = 3e38
+    fs, fi = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols))
+    es, ei = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols), exact_only=True)
+    assert torch.equal(fi, ei)
+    assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
 
 
 def test_item_offset_and_merge_equal_unsharded():

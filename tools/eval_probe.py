@@ -1,26 +1,51 @@
-"""Probe: fused score + mask + top-K at a named shape with random embeddings."""
+"""Probe: fused score + mask + top-K at a named shape with random embeddings; the filtered entry
+point against the exact one (time, equality, users left to the exact pass)."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctypes import c_int32, c_size_t
 import numpy as np, torch
-from recommend_amd import ops, synth
+from recommend_amd import ops, synth, _ffi
 from recommend_amd.evaluator import pairs_to_csr
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="elec"); ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--k", type=int, default=20); ap.add_argument("--dim", type=int, default=64)
+ap.add_argument("--scale", type=float, default=0.1); ap.add_argument("--nomask", action="store_true")
 a = ap.parse_args()
 d = synth.make_named(a.shape)
 tu, ti, _ = d.split(0)
 ptr, cols = pairs_to_csr(tu, ti, d.n_users)
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
-ue = (torch.randn(d.n_users, a.dim, generator=g) * 0.1).to(dev)
-ie = (torch.randn(d.n_items, a.dim, generator=g) * 0.1).to(dev)
+ue = (torch.randn(d.n_users, a.dim, generator=g) * a.scale).to(dev)
+ie = (torch.randn(d.n_items, a.dim, generator=g) * a.scale).to(dev)
 mp, mc = torch.from_numpy(ptr).to(dev), torch.from_numpy(cols).to(dev)
-ops.score_topk(ue, ie, a.k, mp, mc); torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(a.reps): ops.score_topk(ue, ie, a.k, mp, mc)
-e.record(); e.synchronize()
-ms = s.elapsed_time(e) / a.reps
-print(f"score_topk {a.shape} K={a.k}: {ms:.3f} ms  {2.0*d.n_users*d.n_items*a.dim/ms/1e9:.1f} TFLOP/s")
+if a.nomask: mp = mc = None
+lib = _ffi.load()
+ws_bytes = lib.rk_score_topk_ws_bytes(d.n_users, d.n_items, a.dim, a.k)
+ws = torch.zeros(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
+out = {}
+for name in ("rk_score_topk_exact_f32", "rk_score_topk_f32"):
+    os_ = torch.empty((d.n_users, a.k), dtype=torch.float32, device=dev)
+    oi = torch.empty((d.n_users, a.k), dtype=torch.int32, device=dev)
+    def run():
+        _ffi.call(name, ops.ptr(ue), c_int32(d.n_users), ops.ptr(ie), c_int32(d.n_items), c_int32(a.dim),
+                  ops.ptr(mp), ops.ptr(mc), c_int32(a.k), c_int32(0), ops.ptr(os_), ops.ptr(oi), ops.ptr(ws),
+                  c_size_t(ws.numel() * 4), ops.stream_ptr(ue.device))
+    run(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(a.reps): run()
+    e.record(); e.synchronize()
+    ms = s.elapsed_time(e) / a.reps
+    out[name] = (os_, oi)
+    print(f"{name} {a.shape} K={a.k} D={a.dim}: {ms:.3f} ms  {2.0*d.n_users*d.n_items*a.dim/ms/1e9:.1f} TFLOP/s equiv")
+done_off = (ws_bytes - ((4 * d.n_users + 255) // 256) * 256) // 4
+done = ws[done_off:done_off + d.n_users].view(torch.int32)
+print("users left to the exact pass:", int((done == 0).sum()), "of", d.n_users)
+(es, ei), (fs, fi) = out["rk_score_topk_exact_f32"], out["rk_score_topk_f32"]
+print("ids equal:", bool(torch.equal(ei, fi)), " scores bit-equal:", bool(torch.equal(es.view(torch.int32), fs.view(torch.int32))))
+if not torch.equal(ei, fi):
+    bad = (ei != fi).any(1).nonzero().flatten()
+    print("differing users:", bad.numel(), bad[:5].tolist())
+    u = int(bad[0]); print(ei[u].tolist(), fi[u].tolist()); print(es[u].tolist(), fs[u].tolist()); print("done", int(done[u]))
