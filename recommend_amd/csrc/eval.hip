@@ -20,6 +20,7 @@
 // together.  Every lane sees its items in ascending id order and insertion uses a
 // strict '>', so equal scores keep the lower item id first; the merge of the
 // per-slice lists orders by (score desc, id asc) explicitly.
+#include <cstdlib>
 #include "topk_filter.h"
 #include "topk_kernel.h"
 
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void rows_topk_kernel(const float *__restrict_
 // One wavefront per user ranks all n = P*Kin candidates by counting how many
 // beat each one; candidates with rank < K are written to their final slot.
 constexpr int MERGE_MAX = 1024;
+constexpr int kMergeGroup = 16;   // lists per intermediate merge (16 * 32 entries <= MERGE_MAX)
 
 __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, int32_t ib, int jb) {
   const bool va = ia >= 0, vb = ib >= 0;
@@ -64,24 +66,34 @@ __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, in
   return sa > sb || (sa == sb && (ia < ib || (ia == ib && ja < jb)));
 }
 
+// Which rows a merge launch works on (user_list / user_count / gate_cap as for
+// score_topk_kernel); returns false if this wavefront has nothing to do.  rows_per_user > 0 marks
+// the compacted launch, whose rows are rows_per_user per listed user (intermediate merges of groups
+// of lists; the indirection through user_list applies if it is given).
+__device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, const int32_t *user_list,
+                                          const int32_t *user_count, int32_t gate_cap, int32_t rows_per_user,
+                                          int32_t &row_in, int32_t &row_out) {
+  row_in = blockIdx.x * 4 + threadIdx.x / kWave;
+  if (user_count != nullptr) {
+    const int32_t cnt = user_count[0];
+    if (rows_per_user > 0 ? cnt > gate_cap : cnt <= gate_cap) return false;
+    if (rows_per_user > 0) n_rows = min(n_rows, cnt * rows_per_user);
+  }
+  if (row_in >= n_rows) return false;  // wave-uniform; no block barrier in the callers
+  row_out = user_list != nullptr ? user_list[row_in] : row_in;
+  return skip == nullptr || skip[row_out] == 0;   // flagged rows of out are already final
+}
+
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t n, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    float *__restrict__ out_s, int32_t *__restrict__ out_id) {
+    int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
   __shared__ float cs[4][MERGE_MAX];
   __shared__ int32_t ci[4][MERGE_MAX];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int32_t pos = blockIdx.x * 4 + wave;   // row of scores / ids
-  // user_list / user_count / gate_cap as for score_topk_kernel
-  if (user_count != nullptr) {
-    const int32_t cnt = user_count[0];
-    if (user_list == nullptr ? cnt <= gate_cap : cnt > gate_cap) return;
-    if (user_list != nullptr) n_users = min(n_users, cnt);
-  }
-  if (pos >= n_users) return;  // wave-uniform; no block barrier below
-  const int32_t user = user_list != nullptr ? user_list[pos] : pos;   // row of out
-  if (skip != nullptr && skip[user] != 0) return;   // this user's rows of out are already final
+  int32_t pos, user;
+  if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
   for (int c = lane; c < n; c += kWave) {
     cs[wave][c] = scores[(int64_t)pos * n + c];
     ci[wave][c] = ids[(int64_t)pos * n + c];
@@ -93,6 +105,51 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
     const int32_t ic = ci[wave][c];
     int rank = 0;
     for (int j = 0; j < n; ++j) rank += beats(cs[wave][j], ci[wave][j], j, sc, ic, c) ? 1 : 0;
+    if (rank < K) {
+      out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
+      out_id[(int64_t)user * K + rank] = ic;
+    }
+  }
+}
+
+// The same for P lists of Kin entries that are each in final order already -- (score desc, id
+// asc), padding last -- as the lists of score_topk_kernel and of this kernel are.  An entry is
+// beaten by the entries in front of it in its own list and by a prefix of every other list, found
+// by bisection: P * log2(Kin) steps per entry instead of P * Kin.
+__global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
+    const float *__restrict__ scores, const int32_t *__restrict__ ids,
+    int32_t n_users, int32_t P, int32_t Kin, int32_t K, const int32_t *__restrict__ skip,
+    const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
+    int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
+  __shared__ float cs[4][MERGE_MAX];
+  __shared__ int32_t ci[4][MERGE_MAX];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int n = P * Kin;
+  int32_t pos, user;
+  if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
+  for (int c = lane; c < n; c += kWave) {
+    cs[wave][c] = scores[(int64_t)pos * n + c];
+    ci[wave][c] = ids[(int64_t)pos * n + c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
+  for (int c = lane; c < n; c += kWave) {
+    const float sc = cs[wave][c];
+    const int32_t ic = ci[wave][c];
+    const int own = c / Kin;
+    int rank = c - own * Kin;
+    for (int q = 0; q < P; ++q) {
+      if (q == own) continue;
+      int lo = 0, hi = Kin;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1, j = q * Kin + mid;
+        if (beats(cs[wave][j], ci[wave][j], j, sc, ic, c))
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      rank += lo;
+    }
     if (rank < K) {
       out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
       out_id[(int64_t)user * K + rank] = ic;
@@ -210,19 +267,27 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
   return RK_OK;
 }
 
-struct UserSel {   // which users a launch works on; see score_topk_kernel
+struct UserSel {   // which users a launch works on; see score_topk_kernel and merge_row
   const int32_t *skip = nullptr, *list = nullptr, *count = nullptr;
   int32_t cap = 0;
 };
 
+// sorted_lists: every list is in (score desc, id asc) order already, padding last.
+// rows_per_user: see merge_row (0 unless this is an intermediate or final merge of the compacted
+// launch).
 int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_t P, int32_t Kin,
-                int32_t K, const UserSel &sel, float *out_scores, int32_t *out_ids, hipStream_t st) {
+                int32_t K, const UserSel &sel, bool sorted_lists, int32_t rows_per_user, float *out_scores,
+                int32_t *out_ids, hipStream_t st) {
   RK_CHECK_ARG((int64_t)P * Kin <= MERGE_MAX, "too many candidates per user (%lld > %d)",
                (long long)P * Kin, MERGE_MAX);
   RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
-  topk_merge_kernel<<<(int)rk::ceil_div(n_users, 4), 256, 0, st>>>(scores, ids, n_users, P * Kin, K, sel.skip,
-                                                                  sel.list, sel.count, sel.cap, out_scores,
-                                                                  out_ids);
+  const int grid = (int)rk::ceil_div(n_users, 4);
+  if (sorted_lists)
+    topk_merge_sorted_kernel<<<grid, 256, 0, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
+                                                   sel.cap, rows_per_user, out_scores, out_ids);
+  else
+    topk_merge_kernel<<<grid, 256, 0, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
+                                            sel.cap, rows_per_user, out_scores, out_ids);
   RK_CHECK_LAUNCH("topk_merge_kernel");
   return RK_OK;
 }
@@ -250,7 +315,17 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
   }
 #undef RK_EXACT_CASE
   if (rc != RK_OK) return rc;
-  return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, out_scores, out_ids, st);
+  const int32_t rpu = sel.list != nullptr ? 1 : 0;
+  if (nsplit * kp <= MERGE_MAX) return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, rpu, out_scores, out_ids, st);
+  // too many lists for one merge (the compacted launch): groups of kMergeGroup lists first
+  const int groups = nsplit / kMergeGroup;   // open_nsplit() makes this exact
+  float *gs = (float *)(pi + (size_t)n_users * nsplit * kp);
+  int32_t *gi = (int32_t *)(gs + (size_t)n_users * groups * kp);
+  UserSel rows = sel;
+  rows.list = nullptr;
+  if ((rc = merge_lists(ps, pi, n_users * groups, kMergeGroup, kp, kp, rows, true, groups, gs, gi, st)) != RK_OK)
+    return rc;
+  return merge_lists(gs, gi, n_users, groups, kp, K, sel, true, 1, out_scores, out_ids, st);
 }
 
 // Users the filter could not certify are few (ties at the K-th place, degenerate embeddings).
@@ -261,31 +336,53 @@ constexpr int kOpenCap = 1024;
 inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpenCap, rk::ceil_div(n_users, UPB) * UPB); }
 inline int open_nsplit(int32_t n_items, int32_t K) {
   const int64_t tiles = rk::ceil_div(n_items, TI);
-  return (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, (int64_t)MERGE_MAX / kpad_for(K), tiles / 4}));
+  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(128, tiles / 4));
+  if (want * kpad_for(K) <= MERGE_MAX) return (int)want;   // one merge
+  return (int)(want / kMergeGroup * kMergeGroup);          // two: whole groups (want >= 32 here)
+}
+// floats + ints of the compacted launch: its partial lists and the intermediate merge results
+inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
+  const size_t ns = (size_t)open_nsplit(n_items, K);
+  return (size_t)open_positions(n_users) * (ns + ns / kMergeGroup + 1) * kpad_for(K);
 }
 
 // candidate list length of the filter pass for a final K (0: no filter pass, K too large)
-inline int filter_len(int K) { return K + 4 <= 32 ? std::max(8, kpad_for(K + 4)) : 0; }
+// Item slices of the filter launch: as for the exact one, at the filter's occupancy, but at least
+// two where the items allow (measured: a single slice, with every workgroup of the grid walking
+// the table at the same position, runs half as fast per tile), and no more than the exact launch
+// uses (the workspace is sized for that).
+inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
+  int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
+  if (ns == 1 && rk::ceil_div(n_items, TI) >= 8) ns = 2;
+  return std::min(ns, std::max(2, choose_nsplit(n_users, n_items)));
+}
+
+// (8 places of margin between the K-th exact and the last filter score, 4 at least)
+inline int filter_len(int K) { return K + 8 <= 32 ? std::max(8, kpad_for(K + 8)) : (K + 4 <= 32 ? 32 : 0); }
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct TopkWorkspace {
-  size_t part, usplit, isplit, unorm, imax, open_count, open_list, cand_s, cand_id, done, total;
+  size_t part, uhalf, ihalf, unorm, umax, uexp, istats, open_count, stats_part, open_list, cand_s, cand_id, done, total;
 };
 inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
   TopkWorkspace w{};
-  const int nsplit = choose_nsplit(n_users, n_items);
   const int kc = filter_len(K);
+  // (the filter launch may use fewer slices than the exact one, never more)
+  const int nsplit = choose_nsplit(n_users, n_items);
   const size_t klen = (size_t)std::max(kpad_for(K), kc);
   size_t off = 0;
   w.part = off;
-  off += align256(std::max((size_t)n_users * nsplit * klen,
-                           (size_t)open_positions(n_users) * open_nsplit(n_items, K) * kpad_for(K)) * 8);
-  w.usplit = off;  off += align256((size_t)n_users * D * 4);
-  w.isplit = off;  off += align256((size_t)n_items * D * 4);
+  off += align256(std::max((size_t)n_users * std::max(nsplit, 2) * klen,
+                           open_part_entries(n_users, n_items, K)) * 8);
+  w.uhalf = off;   off += align256((size_t)n_users * D * 2);
+  w.ihalf = off;   off += align256((size_t)n_items * D * 2);
   w.unorm = off;   off += align256((size_t)n_users * 4);
-  w.imax = off;    off += 128;   // imax and open_count share one 256-byte block, zeroed together
+  w.umax = off;    off += align256((size_t)n_users * 4);
+  w.uexp = off;    off += align256((size_t)n_users * 4);
+  w.istats = off;  off += 128;   // item statistics and open_count share one 256-byte block, zeroed together
   w.open_count = off; off += 128;
+  w.stats_part = off; off += align256((size_t)2 * rk::kStatSlots * 4);   // follows directly: one memset
   w.open_list = off;  off += align256((size_t)kOpenCap * 4);
   w.cand_s = off;  off += align256((size_t)n_users * std::max(kc, 1) * 4);
   w.cand_id = off; off += align256((size_t)n_users * std::max(kc, 1) * 4);
@@ -324,7 +421,7 @@ int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, 
   RK_CHECK_ARG(n_users >= 0 && P > 0 && Kin > 0 && K > 0, "bad sizes");
   if (n_users == 0) return RK_OK;
   RK_CHECK_ARG(scores && ids && out_scores && out_ids, "null pointer");
-  return merge_lists(scores, ids, n_users, P, Kin, K, UserSel{}, out_scores, out_ids, (hipStream_t)stream);
+  return merge_lists(scores, ids, n_users, P, Kin, K, UserSel{}, false, 0, out_scores, out_ids, (hipStream_t)stream);
 }
 
 int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
@@ -355,28 +452,32 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
   const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
   char *base = (char *)ws;
   const int nsplit = choose_nsplit(n_users, n_items);
-  float *usplit = (float *)(base + w.usplit), *isplit = (float *)(base + w.isplit);
-  float *unorm = (float *)(base + w.unorm), *imax = (float *)(base + w.imax);
+  const int fsplit = filter_nsplit(n_users, n_items, kc, D);
+  float *uhalf = (float *)(base + w.uhalf), *ihalf = (float *)(base + w.ihalf);
+  float *unorm = (float *)(base + w.unorm), *umax = (float *)(base + w.umax), *istats = (float *)(base + w.istats);
+  int32_t *uexp = (int32_t *)(base + w.uexp);
   float *cand_s = (float *)(base + w.cand_s);
   int32_t *cand_id = (int32_t *)(base + w.cand_id), *done = (int32_t *)(base + w.done);
   int32_t *open_count = (int32_t *)(base + w.open_count), *open_list = (int32_t *)(base + w.open_list);
 
-  // 1. split the embeddings into bf16 pairs; user norms and the largest item norm for the bound
-  RK_CHECK_HIP(hipMemsetAsync(imax, 0, 256, st));   // imax and open_count
-  if ((rc = rk::split_rows(Uemb, n_users, D, usplit, unorm, nullptr, st)) != RK_OK) return rc;
-  if ((rc = rk::split_rows(Iemb, n_items, D, isplit, nullptr, imax, st)) != RK_OK) return rc;
+  // 1. fp16 copies of both tables; user norms and the largest item norm for the error bound
+  RK_CHECK_HIP(hipMemsetAsync(istats, 0, 256 + 2 * rk::kStatSlots * 4, st));   // statistics, open_count, partial maxima
+  unsigned int *stats_part = (unsigned int *)(base + w.stats_part);
+  if ((rc = rk::half_rows(Uemb, n_users, D, true, uhalf, unorm, umax, uexp, nullptr, nullptr, st)) != RK_OK) return rc;
+  if ((rc = rk::half_rows(Iemb, n_items, D, false, ihalf, nullptr, nullptr, nullptr, stats_part, istats, st)) != RK_OK)
+    return rc;
   // 2. the kc best filter scores per user (local item ids)
   float *ps = (float *)(base + w.part);
-  int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kc);
-  const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
-  if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, usplit, n_users, isplit, n_items, mask_ptr, mask_items,
-                                   nsplit, ps, pi)) != RK_OK)
+  int32_t *pi = (int32_t *)(ps + (size_t)n_users * fsplit * kc);
+  const int grid = (int)rk::ceil_div(n_users, UPB) * fsplit;
+  if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, uhalf, n_users, ihalf, n_items, mask_ptr, mask_items,
+                                   fsplit, ps, pi)) != RK_OK)
     return rc;
-  if ((rc = merge_lists(ps, pi, n_users, nsplit, kc, std::min(kc, n_items), UserSel{}, cand_s, cand_id, st)) != RK_OK)
+  if ((rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, 0, cand_s, cand_id, st)) != RK_OK)
     return rc;
   // 3. exact scores of the candidates, final order, certification
   if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, std::min(kc, n_items), K, unorm,
-                                  imax, item_id_offset, out_scores, out_ids, done, open_count, open_list,
+                                  uexp, istats, item_id_offset, out_scores, out_ids, done, open_count, open_list,
                                   kOpenCap, st)) != RK_OK)
     return rc;
   // 4. the exact kernel for the users that could not be certified: the listed ones as a compact

@@ -2,63 +2,135 @@
 //
 // The exact scores are fp32 fma chains on v_mfma_f32_32x32x2_f32, which runs at the vector-ALU
 // rate and shares the issue port with the selection code.  Most of that work is spent on items
-// that are nowhere near a user's top K.  The filter computes every score to 16 bits instead: each
-// embedding is split into two bf16 numbers, x ~ h + m, and u.i ~ u_h.i_h + u_h.i_m + u_m.i_h on
-// v_mfma_f32_32x32x16_bf16 (three matrix-pipe instructions of 32 cycles per 16 k, against
-// eight of 64 cycles).  The same fused kernel keeps the K+4.. best filter scores per user; those
-// candidates are then scored exactly (the documented fp32 chain, bit for bit), ranked by
-// (score desc, id asc), and CERTIFIED: with |filter - exact| <= eps for every item, no item
-// outside the candidates can reach the K-th exact score if (smallest candidate filter score) + eps
-// is below it.  Users that fail the test (ties at the boundary, pathological data) are ranked by
-// the exact kernel afterwards; it skips wavefronts whose users are all certified.  The result is
+// that are nowhere near a user's top K.  The filter computes every score in fp16 instead: both
+// tables are copied to fp16 (scaled by powers of two into its range: every user row by its own
+// exponent, the item table by one), and u.i comes from v_mfma_f32_32x32x16_f16 -- one
+// matrix-pipe instruction of 32 cycles per 16 k against eight of 64 cycles.  The same fused kernel
+// keeps the K+8 best filter scores per user; those candidates are then scored exactly (the
+// documented fp32 chain, bit for bit), ranked by (score desc, id asc), and CERTIFIED: with
+// |filter - exact| <= eps for every item, no item outside the candidates can reach the K-th exact
+// score if (smallest candidate filter score) + eps is below it.  Users that fail the test (ties at
+// the boundary, pathological data) are ranked by the exact kernel afterwards.  The result is
 // therefore the exact kernel's result in every case.
+#include <hip/hip_fp16.h>
+
 #include "topk_filter.h"
 #include "topk_kernel.h"
 
 namespace {
 
-// round-to-nearest-even bf16 of a finite float, as its 16-bit pattern
-__device__ __forceinline__ uint32_t bf16_bits(float x) {
-  const uint32_t u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+// exponent e with |x| * 2^-e in [0.5, 1) (0 for x = 0, inf, nan): rows scaled by 2^-e use the
+// top of the fp16 range without overflowing
+__device__ __forceinline__ int scale_exponent(float maxabs) {
+  if (!(maxabs > 0.0f) || !(maxabs < INFINITY)) return 0;
+  int e;
+  (void)frexpf(maxabs, &e);
+  return e;
 }
 
-// one thread per 8 consecutive elements of a row: 16 B of high parts and 16 B of remainders
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int64_t n_rows, int D,
-                                                         float *__restrict__ split, float *__restrict__ norms,
-                                                         float *__restrict__ max_norm) {
-  const int per_row = D / 8;                               // 8 (D = 64) or 16 (D = 128) threads per row
+// per-row statistics: one thread per 8 consecutive elements, the D/8 threads of a row in adjacent
+// lanes.  norms[row] = |x|, row_maxabs[row] = max |x_k| (may be NULL); stats_part (may be NULL;
+// 2 x kStatSlots, zeroed by the caller): partial maxima of the norms and of |x_k| over the table,
+// spread over many slots because thousands of wavefronts hitting one address serialise
+// (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ X, int64_t n_rows, int D,
+                                                        float *__restrict__ norms,
+                                                        float *__restrict__ row_maxabs,
+                                                        unsigned int *__restrict__ stats_part) {
+  const int per_row = D / 8;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / per_row;
   const int seg = (int)(t % per_row);
-  float ss = 0.0f;
+  float ss = 0.0f, mx = 0.0f;
   if (row < n_rows) {
     const float4 a = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg);
     const float4 b = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint32_t h[8], m[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      h[j] = bf16_bits(v[j]);
-      m[j] = bf16_bits(v[j] - __uint_as_float(h[j] << 16));   // the subtraction is exact in fp32
       ss = fmaf(v[j], v[j], ss);
+      // a NaN must not get lost in the maximum: it makes the norm NaN already, which is what
+      // disables certification
+      mx = fmaxf(mx, fabsf(v[j]));
     }
-    uint4 hp, mp;
-    hp.x = h[0] | (h[1] << 16); hp.y = h[2] | (h[3] << 16); hp.z = h[4] | (h[5] << 16); hp.w = h[6] | (h[7] << 16);
-    mp.x = m[0] | (m[1] << 16); mp.y = m[2] | (m[3] << 16); mp.z = m[4] | (m[5] << 16); mp.w = m[6] | (m[7] << 16);
-    float *out = split + row * D;                          // D bf16 = D/2 floats per plane
-    *reinterpret_cast<uint4 *>(out + 4 * seg) = hp;
-    *reinterpret_cast<uint4 *>(out + D / 2 + 4 * seg) = mp;
   }
-  if (norms == nullptr && max_norm == nullptr) return;
-  // the per_row threads of a row sit in adjacent lanes (per_row divides 64)
-  for (int off = per_row / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, rk::kWave);
+  for (int off = per_row / 2; off > 0; off >>= 1) {
+    ss += __shfl_xor(ss, off, rk::kWave);
+    mx = fmaxf(mx, __shfl_xor(mx, off, rk::kWave));
+  }
+  const float nrm = sqrtf(ss);
   if (row < n_rows && seg == 0) {
-    const float nrm = sqrtf(ss);
     if (norms) norms[row] = nrm;
-    // non-negative floats order like their bit patterns
-    if (max_norm) atomicMax(reinterpret_cast<unsigned int *>(max_norm), __float_as_uint(nrm));
+    if (row_maxabs) row_maxabs[row] = mx;
   }
+  if (stats_part) {
+    // one pair of atomics per wavefront; the maxima are taken on the bit patterns, so that a NaN
+    // (above every number as an unsigned pattern) survives and reaches the error bound
+    unsigned int bn = row < n_rows ? __float_as_uint(nrm) & 0x7FFFFFFFu : 0u;
+    unsigned int bm = row < n_rows ? __float_as_uint(mx) : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      bn = max(bn, (unsigned int)__shfl_xor((int)bn, off, rk::kWave));
+      bm = max(bm, (unsigned int)__shfl_xor((int)bm, off, rk::kWave));
+    }
+    if (threadIdx.x % rk::kWave == 0) {
+      const int slot = (blockIdx.x * 4 + threadIdx.x / rk::kWave) % rk::kStatSlots;
+      atomicMax(stats_part + slot, bn);
+      atomicMax(stats_part + rk::kStatSlots + slot, bm);
+    }
+  }
+}
+
+// table_stats[0] = largest norm, table_stats[1] = largest |x_k|
+__global__ __launch_bounds__(rk::kStatSlots) void table_stats_kernel(const unsigned int *__restrict__ stats_part,
+                                                                      float *__restrict__ table_stats) {
+  __shared__ unsigned int red[2][rk::kStatSlots / rk::kWave];
+  unsigned int bn = stats_part[threadIdx.x], bm = stats_part[rk::kStatSlots + threadIdx.x];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    bn = max(bn, (unsigned int)__shfl_xor((int)bn, off, rk::kWave));
+    bm = max(bm, (unsigned int)__shfl_xor((int)bm, off, rk::kWave));
+  }
+  if (threadIdx.x % rk::kWave == 0) {
+    red[0][threadIdx.x / rk::kWave] = bn;
+    red[1][threadIdx.x / rk::kWave] = bm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned int b = 0;
+    for (int i = 0; i < rk::kStatSlots / rk::kWave; ++i) b = max(b, red[threadIdx.x][i]);
+    table_stats[threadIdx.x] = __uint_as_float(b);
+  }
+}
+
+// X[n_rows][D] fp32 -> fp16 rows of x * 2^-e, round to nearest even; e = the row's own exponent
+// (row_maxabs given; written to row_exp) or the table's (table_stats[1]).  One thread per 8
+// elements = 16 bytes of output.
+__global__ __launch_bounds__(256) void to_half_rows_kernel(const float *__restrict__ X, int64_t n_rows, int D,
+                                                           const float *__restrict__ row_maxabs,
+                                                           const float *__restrict__ table_stats,
+                                                           __half *__restrict__ out,
+                                                           int32_t *__restrict__ row_exp) {
+  const int per_row = D / 8;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / per_row;
+  const int seg = (int)(t % per_row);
+  if (row >= n_rows) return;
+  const int e = scale_exponent(row_maxabs ? row_maxabs[row] : table_stats[1]);
+  if (row_exp && seg == 0) row_exp[row] = e;
+  const float sc = ldexpf(1.0f, -e);   // e in [-148, 128]: exact, possibly subnormal
+  const float4 a = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg);
+  const float4 b = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg + 4);
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // (two multiplications by powers of two when the scale itself would overflow fp32)
+    const float x0 = e > 126 ? v[2 * j] * 0.5f * ldexpf(1.0f, 1 - e) : v[2 * j] * sc;
+    const float x1 = e > 126 ? v[2 * j + 1] * 0.5f * ldexpf(1.0f, 1 - e) : v[2 * j + 1] * sc;
+    w[j] = (uint32_t)__half_as_ushort(__float2half_rn(x0)) | ((uint32_t)__half_as_ushort(__float2half_rn(x1)) << 16);
+  }
+  *reinterpret_cast<uint4 *>(out + row * D + 8 * seg) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // the documented exact score: one fmaf per product, k = 0,32,1,33,...,31,63 inside each block of
@@ -66,9 +138,16 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 __device__ __forceinline__ float exact_score(const float *__restrict__ u, const float *__restrict__ it, int D) {
   float acc = 0.0f;
   for (int c = 0; c < D / 64; ++c)
-    for (int m = 0; m < 32; ++m) {
-      acc = fmaf(it[64 * c + m], u[64 * c + m], acc);
-      acc = fmaf(it[64 * c + 32 + m], u[64 * c + 32 + m], acc);
+#pragma unroll 2
+    for (int m = 0; m < 32; m += 4) {
+      const float4 ia = *reinterpret_cast<const float4 *>(it + 64 * c + m);
+      const float4 ib = *reinterpret_cast<const float4 *>(it + 64 * c + 32 + m);
+      const float4 ua = *reinterpret_cast<const float4 *>(u + 64 * c + m);
+      const float4 ub = *reinterpret_cast<const float4 *>(u + 64 * c + 32 + m);
+      acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
+      acc = fmaf(ia.y, ua.y, acc); acc = fmaf(ib.y, ub.y, acc);
+      acc = fmaf(ia.z, ua.z, acc); acc = fmaf(ib.z, ub.z, acc);
+      acc = fmaf(ia.w, ua.w, acc); acc = fmaf(ib.w, ub.w, acc);
     }
   return acc;
 }
@@ -80,50 +159,57 @@ __device__ __forceinline__ bool ranks_before(float sa, int32_t ia, float sb, int
   return sa > sb || (sa == sb && ia < ib);
 }
 
-// one wavefront per user, one lane per candidate (kc <= 32)
+// half a wavefront per user, one lane per candidate (kc <= 32)
 __global__ __launch_bounds__(256) void refine_kernel(
     const float *__restrict__ Uemb, const float *__restrict__ Iemb, int32_t n_users, int32_t n_items, int D,
     const float *__restrict__ cand_s, const int32_t *__restrict__ cand_id, int kc, int K,
-    const float *__restrict__ unorm, const float *__restrict__ imax, int32_t item_id_offset,
-    float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
+    const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
+    int32_t item_id_offset, float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
     int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
   const int wave = threadIdx.x / rk::kWave, lane = threadIdx.x % rk::kWave;
-  const int32_t user = blockIdx.x * 4 + wave;
-  if (user >= n_users) return;
+  const int sub = lane >> 5, l32 = lane & 31;
+  if ((blockIdx.x * 4 + wave) * 2 >= n_users) return;   // wave-uniform
+  const int32_t user = (blockIdx.x * 4 + wave) * 2 + sub;
+  const bool user_ok = user < n_users;
   int32_t id = -1;
   float approx = -INFINITY;
-  if (lane < kc) {
-    id = cand_id[(int64_t)user * kc + lane];
-    approx = cand_s[(int64_t)user * kc + lane];
+  if (user_ok && l32 < kc) {
+    id = cand_id[(int64_t)user * kc + l32];
+    approx = cand_s[(int64_t)user * kc + l32];
   }
   const bool valid = id >= 0;
+  const bool masked = approx == kMasked;   // (a product of fp16 rows is at most D in magnitude)
   float s = -INFINITY;
-  if (valid) s = approx == kMasked ? kMasked : exact_score(Uemb + (int64_t)user * D, Iemb + (int64_t)id * D, D);
+  if (valid) s = masked ? kMasked : exact_score(Uemb + (int64_t)user * D, Iemb + (int64_t)id * D, D);
   // rank among the candidates by (score desc, id asc); ids are distinct
   int rank = 0;
   for (int l = 0; l < kc; ++l) {
-    const float sl = __shfl(s, l, rk::kWave);
-    const int32_t il = __shfl(id, l, rk::kWave);
+    const float sl = __shfl(s, l, 32);
+    const int32_t il = __shfl(id, l, 32);
     rank += ranks_before(sl, il, s, id) ? 1 : 0;
   }
   if (valid && rank < K) {
     out_s[(int64_t)user * K + rank] = s;
     out_id[(int64_t)user * K + rank] = id + item_id_offset;
   }
-  // certification
-  const int n_valid = __popcll(__ballot(valid));
-  float a_min = valid ? approx : INFINITY;
+  // certification, in the units of the exact scores: the filter worked on u * 2^-eu and i * 2^-ei
+  const int e_sum = (user_ok ? uexp[user] : 0) + scale_exponent(istats[1]);
+  const float back = ldexpf(1.0f, e_sum);           // inf / 0 at absurd magnitudes: nothing certified
+  const int n_valid = __popc((uint32_t)(__ballot(valid) >> (32 * sub)));
+  float a_min = valid ? (masked ? kMasked : approx * back) : INFINITY;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) a_min = fminf(a_min, __shfl_xor(a_min, off, rk::kWave));
-  const uint64_t kth = __ballot(valid && rank == K - 1);
-  const float tau = kth ? __shfl(s, __ffsll((long long)kth) - 1, rk::kWave) : INFINITY;
-  if (lane == 0) {
-    // |filter - exact| <= 2^-12 |u| max|i|: the split leaves 2^-18 of each factor and the dropped
-    // u_m.i_m term is of the same size (3 * 2^-18 together), 3D fp32 additions of the filter add at
-    // most 2^-15.4 and the D roundings of the exact chain 2^-17 (D = 128): 2^-14.5, and a five-fold
-    // margin on top.  The absolute term covers flushed denormals.  Non-finite embeddings make the
-    // norms, hence eps, infinite or NaN: nothing is certified and the exact kernel ranks everyone.
-    const float eps = 0x1p-12f * unorm[user] * imax[0] + 1e-30f;
+  for (int off = 16; off > 0; off >>= 1) a_min = fminf(a_min, __shfl_xor(a_min, off, 32));
+  const uint32_t kth = (uint32_t)(__ballot(valid && rank == K - 1) >> (32 * sub));
+  const float tau_l = __shfl(s, kth ? __ffs((int)kth) - 1 : 0, 32);
+  const float tau = kth ? tau_l : INFINITY;
+  if (l32 == 0 && user_ok) {
+    // |filter - exact| <= eps.  Rounding an element to fp16 changes it by at most 2^-11 of itself
+    // (normal range) or 2^-25 (below 2^-14, after scaling): |du.i| + |u.di| + |du.di| <=
+    // (2^-10 + 2^-22) |u| |i| + 2D 2^-25 2^(eu+ei); the fp32 accumulations of the filter and of the
+    // exact chain add at most 2D 2^-24 |u| |i| = 2^-16 (D = 128).  1.25 * 2^-10 and D * 2^-22 bound
+    // the two groups with a margin.  Non-finite embeddings make a norm, hence eps, infinite or NaN:
+    // nothing is certified then and the exact kernel ranks everyone.
+    const float eps = 1.25f * 0x1p-10f * unorm[user] * istats[0] + (float)D * 0x1p-22f * back + 1e-30f;
     const bool ok = kc >= n_items || n_valid < kc || a_min + eps < tau;
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
@@ -157,12 +243,21 @@ int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_u
 
 namespace rk {
 
-int split_rows(const float *X, int64_t n_rows, int D, float *split, float *norms, float *max_norm,
-               hipStream_t st) {
+int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *out, float *norms,
+              float *row_maxabs, int32_t *row_exp, unsigned int *stats_part, float *table_stats,
+              hipStream_t st) {
   if (n_rows == 0) return RK_OK;
-  const int64_t threads = n_rows * (D / 8);
-  split_rows_kernel<<<(unsigned)ceil_div(threads, 256), 256, 0, st>>>(X, n_rows, D, split, norms, max_norm);
-  RK_CHECK_LAUNCH("split_rows_kernel");
+  const unsigned grid = (unsigned)ceil_div(n_rows * (D / 8), 256);
+  row_stats_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, norms, per_row_scale ? row_maxabs : nullptr,
+                                         per_row_scale ? nullptr : stats_part);
+  RK_CHECK_LAUNCH("row_stats_kernel");
+  if (!per_row_scale) {
+    table_stats_kernel<<<1, kStatSlots, 0, st>>>(stats_part, table_stats);
+    RK_CHECK_LAUNCH("table_stats_kernel");
+  }
+  to_half_rows_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, per_row_scale ? row_maxabs : nullptr, table_stats,
+                                            (__half *)out, per_row_scale ? row_exp : nullptr);
+  RK_CHECK_LAUNCH("to_half_rows_kernel");
   return RK_OK;
 }
 
@@ -183,11 +278,11 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
                       const float *cand_s, const int32_t *cand_id, int kc, int K, const float *unorm,
-                      const float *imax, int32_t item_id_offset, float *out_s, int32_t *out_id,
-                      int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
-                      hipStream_t st) {
-  refine_kernel<<<(unsigned)ceil_div(n_users, 4), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, kc, K,
-                                                                 unorm, imax, item_id_offset, out_s, out_id, done,
+                      const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
+                      int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
+                      int32_t open_cap, hipStream_t st) {
+  refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, kc, K,
+                                                                 unorm, uexp, istats, item_id_offset, out_s, out_id, done,
                                                                  open_count, open_list, open_cap);
   RK_CHECK_LAUNCH("refine_kernel");
   return RK_OK;

@@ -1,17 +1,22 @@
 // Internal interface between eval.hip (exact kernels, entry points) and eval_filter.hip (the
-// bf16 x 2 candidate filter and the exact re-scoring of its candidates).
+// fp16 candidate filter and the exact re-scoring of its candidates).
 #pragma once
 #include "common.h"
 
 namespace rk {
 
-// X[n_rows][D] fp32 -> rows of the same byte size [D bf16 high parts | D bf16 remainders];
-// norms (may be NULL): per-row Euclidean norm; max_norm (may be NULL, zeroed by the caller): the
-// largest row norm.
-int split_rows(const float *X, int64_t n_rows, int D, float *split, float *norms, float *max_norm,
-               hipStream_t st);
+constexpr int kStatSlots = 1024;
 
-// The fused top-K kernel on split rows: per user and item slice the kc best FILTER scores,
+// X[n_rows][D] fp32 -> out[n_rows][D] fp16 of x * 2^-e.  per_row_scale: e is the row's own
+// exponent (written to row_exp; row_maxabs: n_rows floats of scratch), norms gets the rows'
+// Euclidean norms.  Otherwise e is the exponent of the table's largest |x|, and table_stats
+// receives [0] the largest row norm, [1] the largest |x| (stats_part: 2 * kStatSlots words of
+// scratch, zeroed by the caller).
+int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *out, float *norms,
+              float *row_maxabs, int32_t *row_exp, unsigned int *stats_part, float *table_stats,
+              hipStream_t st);
+
+// The fused top-K kernel on fp16 rows: per user and item slice the kc best FILTER scores,
 // item ids local to this table.
 int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Usplit, int32_t n_users,
                        const float *Isplit, int32_t n_items, const int32_t *mask_ptr,
@@ -24,7 +29,7 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 // in open_count[0] (zeroed by the caller) and the first open_cap of them listed in open_list.
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
                       const float *cand_s, const int32_t *cand_id, int kc, int K, const float *unorm,
-                      const float *imax, int32_t item_id_offset, float *out_s, int32_t *out_id,
+                      const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s, int32_t *out_id,
                       int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
                       hipStream_t st);
 

@@ -8,7 +8,7 @@ namespace {
 using rk::kWave;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int TI = 32;     // items per LDS tile (MFMA rows)
 constexpr int UPW = 64;    // users per wavefront
@@ -22,7 +22,7 @@ __host__ __device__ inline int kpad_for(int K) { return K <= 4 ? 4 : (K + 3) / 4
 
 // Item slices per user tile.  Every slice restarts its lists from nothing and pays the K*ln(n/K)
 // insertions of a streaming top-K again, so fewer slices are cheaper; what slices buy is a grid
-// that fills the chip evenly.  The estimate below is launch rounds (two workgroups fit a CU)
+// that fills the chip evenly.  The estimate below is launch rounds (wgs_per_cu workgroups fit a CU)
 // times the work per round, with 4 % of a slice's time charged per extra slice.
 inline int cu_count() {
   static int cached = 0;
@@ -36,10 +36,15 @@ inline int cu_count() {
   return cached;
 }
 
-inline int choose_nsplit(int n_users, int n_items) {
+// workgroups of score_topk_kernel a CU holds (registers: 512 / waves per SIMD each)
+__host__ __device__ constexpr int wg_per_cu(int kpad, int dc, bool filter) {
+  return filter ? (dc == 1 ? 3 : 2) : (dc == 1 && kpad <= 24 ? 2 : 1);
+}
+
+inline int choose_nsplit(int n_users, int n_items, int wgs_per_cu = 2) {
   const int64_t utiles = rk::ceil_div(n_users, UPB);
   const int64_t tiles = rk::ceil_div(n_items, TI);
-  const int64_t slots = 2 * (int64_t)cu_count();
+  const int64_t slots = wgs_per_cu * (int64_t)cu_count();
   int best = 1;
   double best_cost = 0.0;
   for (int ns = 1; ns <= 16; ++ns) {  // ns * 32 <= MERGE_MAX
@@ -87,11 +92,12 @@ struct LaneList {
 };
 
 // FILTER = false: Uemb / Iemb are the fp32 embeddings and a score is the exact fp32 fma chain.
-// FILTER = true: they point at "split" rows of the same byte size, [D bf16 high parts | D bf16
-// remainders] (x ~ h + m to 16 bits), and a score is u_h.i_h + u_h.i_m + u_m.i_h on
-// v_mfma_f32_32x32x16_bf16 -- a filter score within 2^-14 * |u| * |i| of the exact one, used to
-// pick candidates that are then re-scored exactly.  The bf16 MFMA runs on the matrix pipe, which
-// (unlike the fp32-input MFMA) the selection's vector instructions overlap with.
+// FILTER = true: they point at fp16 copies of the rows (D halfs per row, scaled by powers of two
+// into the fp16 range) and a score is their product on v_mfma_f32_32x32x16_f16 -- a filter score
+// within 2^-10 * |u| * |i| of the exact one (times the scale), used to pick candidates that are
+// then re-scored exactly.  The fp16 MFMA runs on the matrix pipe, which (unlike the fp32-input
+// MFMA) the selection's vector instructions overlap with, and one of them covers 16 k where the
+// fp32 form needs eight instructions of twice the length.
 // skip (may be NULL): users with a non-zero flag need no result; a wavefront whose 64 users are
 // all flagged returns at once.
 // user_list / user_count / gate_cap select which users the launch works on:
@@ -102,7 +108,7 @@ struct LaneList {
 //     the mask); part_* rows are positions; nothing runs if *user_count > gate_cap.  n_users is
 //     then the number of positions the grid covers.
 template <int KPAD, int DC, bool FILTER>
-__global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_topk_kernel(
+__global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_kernel(
     const float *__restrict__ Uemb, int32_t n_users,
     const float *__restrict__ Iemb, int32_t n_items,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   constexpr int RN = 4;   // tiles per stage
   __shared__ __attribute__((aligned(1024))) float tile0[FILTER ? 1 : 4][FILTER ? 1 : TI * D];
   __shared__ __attribute__((aligned(1024))) float tile1[FILTER ? 1 : 4][FILTER ? 1 : TI * D];
-  __shared__ __attribute__((aligned(1024))) float ring[FILTER ? 2 * RN : 1][FILTER ? TI * D : 1];
+  __shared__ __attribute__((aligned(1024))) float ring[FILTER ? 2 * RN : 1][FILTER ? TI * D / 2 : 1];
   // candidate queues: [wave][0] scores, [wave][1] item ids (one array, so that a score and its
   // id, a fixed distance apart, go out in one ds_write2)
   __shared__ uint32_t queue[4][2][QS][kWave];
@@ -158,31 +164,23 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   const int32_t t_hi = (int32_t)((int64_t)tiles_total * (split + 1) / nsplit);
 
   // user fragments B[k][j = col]: chain A multiplies users ubase+col, chain B users ubase+32+col.
-  // fp32: this lane holds k = 64c + 32*half + m.  Split rows: 16 k per MFMA, this lane holds
-  // k = 16*kb + 8*half + 0..7 of the high parts (uh) and of the remainders (um).
+  // fp32: this lane holds k = 64c + 32*half + m.  fp16 rows: 16 k per MFMA, this lane holds
+  // k = 16*kb + 8*half + 0..7.
   constexpr int KB = D / 16;
   float bfa[FILTER ? 1 : DC][FILTER ? 1 : 32], bfb[FILTER ? 1 : DC][FILTER ? 1 : 32];
-  bf16x8 uha[FILTER ? KB : 1], uma[FILTER ? KB : 1], uhb[FILTER ? KB : 1], umb[FILTER ? KB : 1];
+  half8 uha[FILTER ? KB : 1], uhb[FILTER ? KB : 1];
   if constexpr (FILTER) {
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      uint4 ha = zero, ma = zero, hb = zero, mb = zero;
-      const int64_t off = (16 * kb + 8 * half) / 2;   // in floats: 8 bf16 = 4 floats
-      if (ubase + col < n_users) {
-        const float *row = Uemb + row_a * D;
-        ha = *reinterpret_cast<const uint4 *>(row + off);
-        ma = *reinterpret_cast<const uint4 *>(row + D / 2 + off);
-      }
-      if (ubase + 32 + col < n_users) {
-        const float *row = Uemb + row_b * D;
-        hb = *reinterpret_cast<const uint4 *>(row + off);
-        mb = *reinterpret_cast<const uint4 *>(row + D / 2 + off);
-      }
-      uha[kb] = __builtin_bit_cast(bf16x8, ha);
-      uma[kb] = __builtin_bit_cast(bf16x8, ma);
-      uhb[kb] = __builtin_bit_cast(bf16x8, hb);
-      umb[kb] = __builtin_bit_cast(bf16x8, mb);
+      uint4 ha = zero, hb = zero;
+      const int64_t off = (2 * kb + half) * 16;   // bytes
+      if (ubase + col < n_users)
+        ha = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(Uemb) + row_a * (D * 2) + off);
+      if (ubase + 32 + col < n_users)
+        hb = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(Uemb) + row_b * (D * 2) + off);
+      uha[kb] = __builtin_bit_cast(half8, ha);
+      uhb[kb] = __builtin_bit_cast(half8, hb);
     }
   } else {
 #pragma unroll
@@ -218,7 +216,11 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
     }
     mcur = lo;
   }
+  // The cursor holds the next TWO masked items: the entry consumed in a tile was loaded at
+  // least one consumption earlier, so the loop below does not sit out a memory round trip
+  // (behind every DMA in flight -- the counter is in order) for each masked item of the tile.
   int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+  int32_t next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
 
   LaneList<KPAD> list;
   list.init();
@@ -226,18 +228,26 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   int qc = 0;
 
   // Tile staging by LDS-DMA: one wave-instruction writes 64 x 16 B = 1 KiB of LDS linearly from
-  // per-lane global addresses; slot s of row r holds chunk s ^ (r & 15) of that item's embedding.
-  constexpr int CPR = D / 4;     // 16-byte chunks per row
-  constexpr int RPP = 64 / CPR;  // rows per 1-KiB piece
+  // per-lane global addresses.  Rows are RB bytes; slot s of row r holds 16-byte chunk
+  // s ^ swz(r) of that item's row, where swz spreads the rows that share LDS banks (16 rows of
+  // 256 B: r & 15; 128-byte rows alias in pairs: (r >> 1) & 7), so that the b128 fragment reads
+  // of 32 rows at one chunk index are conflict-free.
+  constexpr int RB = FILTER ? D * 2 : D * 4;   // bytes per row
+  constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+  constexpr int SW = CPR < 16 ? CPR : 16;      // chunks a swizzle permutes
+  constexpr int RPP = 64 / CPR;                // rows per 1-KiB piece
   constexpr int PIECES = TI / RPP;
+  static_assert(RB == 128 || RB % 256 == 0, "swizzle written for 128-byte rows and multiples of 256");
+  auto swz = [](int r) { return RB == 128 ? (r >> 1) & 7 : r & 15; };
   // A full tile is one contiguous block of the table: the per-lane byte offset of piece p is a
-  // loop-invariant pattern XOR a per-piece constant (rows p*RPP + l with l < RPP never carry into
-  // the bits that p*RPP sets), so a piece costs one XOR besides the DMA instruction itself.
+  // loop-invariant pattern XOR a per-piece constant (swz(p*RPP + l) = swz(p*RPP) ^ swz(l) for
+  // l < RPP: the two never set the same bits), so a piece costs one XOR besides the DMA itself.
   // Exact: a wavefront issues all pieces of its private tile.  Filter: piece range NP*wave..
   constexpr int NP = FILTER ? PIECES / 4 : PIECES;
+  static_assert(NP >= 1, "a tile has at least one piece per wavefront");
   const int pbase = FILTER ? __builtin_amdgcn_readfirstlane(wave) * NP : 0;
   const int l_row = lane / CPR, l_slot = lane % CPR;
-  uint32_t lane_off = (uint32_t)(l_row * D * 4 + (((l_slot & ~15) | ((l_slot & 15) ^ l_row)) * 16));
+  uint32_t lane_off = (uint32_t)(l_row * RB + (((l_slot & ~(SW - 1)) | ((l_slot & (SW - 1)) ^ swz(l_row))) * 16));
   // The DMA instructions are inline assembly, and on purpose: the compiler's wait-count pass
   // tracks LDS-DMA per LDS array and makes later reads of an array wait for "its" DMAs, but with
   // four buffers and the loads of the mask cursor in between it falls back to vmcnt(0) in front
@@ -259,11 +269,11 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)dst + (uint32_t)pbase * 1024u);
     if ((t + 1) * TI <= n_items) {
-      const char *tile_base = reinterpret_cast<const char *>(Iemb + (int64_t)t * TI * D) + (int64_t)pbase * 1024;
+      const char *tile_base = reinterpret_cast<const char *>(Iemb) + (int64_t)t * TI * RB + (int64_t)pbase * 1024;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int p = pbase + j;
-        const uint32_t off = (lane_off ^ (uint32_t)(((p * RPP) & 15) * 16)) + (uint32_t)(j * 1024);
+        const uint32_t off = (lane_off ^ (uint32_t)(swz(p * RPP) * 16)) + (uint32_t)(j * 1024);
         dma_piece(tile_base, off, lds0 + (uint32_t)(j * 1024));
       }
       return;
@@ -273,9 +283,9 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int p = pbase + j;
-      const uint32_t off = lane_off ^ (uint32_t)(((p * RPP) & 15) * 16);
-      const int32_t item = min(t * TI + p * RPP + (int32_t)(off / (D * 4)), n_items - 1);
-      dma_piece_lane(reinterpret_cast<const char *>(Iemb + (int64_t)item * D) + (off & (D * 4 - 1)),
+      const uint32_t off = lane_off ^ (uint32_t)(swz(p * RPP) * 16);
+      const int32_t item = min(t * TI + p * RPP + (int32_t)(off / RB), n_items - 1);
+      dma_piece_lane(reinterpret_cast<const char *>(Iemb) + (int64_t)item * RB + (off & (RB - 1)),
                      lds0 + (uint32_t)(j * 1024));
     }
   };
@@ -317,9 +327,6 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
     float m;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v0), "v"(v1), "v"(v2));
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v3));
-#ifdef RK_EXP_NOSEL
-    list.s[0] = fmaxf(list.s[0], m); return;
-#endif
     if (!__any(m > thr)) return;
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -333,11 +340,11 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   };
 
   // fp32 rows: slot 16c + ((8*half + q) ^ (col & 15)) of row col; q < 8 only touches bits the other
-  // terms leave alone, so the eight addresses are one per-lane value XOR q*16.  Split rows: the
-  // 16-byte chunk of k-block kb is 2*kb + half in the high-part plane (the remainder plane follows
-  // D*2 bytes later); again the lane part (half) and the static part (2*kb) use different bits.
-  uint32_t frag_off = FILTER ? (uint32_t)(col * D * 4 + (half ^ (col & 15)) * 16)
-                             : (uint32_t)(col * D * 4 + ((8 * half) ^ (col & 15)) * 16);
+  // terms leave alone, so the eight addresses are one per-lane value XOR q*16.  fp16 rows: the
+  // 16-byte chunk of k-block kb is 2*kb + half; again the lane part (half, the swizzle) and the
+  // static part (2*kb) combine by XOR.
+  uint32_t frag_off = FILTER ? (uint32_t)(col * RB + (half ^ swz(col)) * 16)
+                             : (uint32_t)(col * RB + ((8 * half) ^ (col & 15)) * 16);
   // Lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in acc_b.
   // After the swap every lane holds, for ITS user (ubase + lane), rows (r&3)+8*(r>>2) in lo[r]
   // and rows 4+(r&3)+8*(r>>2) in hi[r].
@@ -352,11 +359,9 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
       lo[r] = acc_a[r];
       hi[r] = acc_b[r];
     }
-#ifndef RK_EXP_NOSWAP
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
-#endif
   };
   // scores of tile t that do not rank as computed: rows past the end of the item table (never),
   // training interactions of this lane's user (the mask score)
@@ -374,7 +379,8 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
       while (next_m < item0 + TI) {
         mbits |= 1u << (next_m - item0);
         ++mcur;
-        next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+        next_m = next2_m;
+        next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -395,111 +401,65 @@ __global__ __launch_bounds__(256, (DC == 1 && KPAD <= 24) ? 2 : 1) void score_to
   };
 
   if constexpr (FILTER) {
-    // The filter's multiplications run on the matrix pipe next to the vector instructions of the
-    // selection, so the loop is software-pipelined inside the wavefront: while the scores of tile
-    // t (already in lo/hi) are selected, the MFMAs of tile t+1 are issued in 8 parts, one in
-    // front of each group of four scores.
+    // The tiles come through a ring of two stages of RN tiles.  Before the first tile of a stage
+    // is read every wavefront waits for its own quarters of that stage (issued a whole stage
+    // earlier) and meets the others at the barrier; the barrier also says that everybody is done
+    // with the previous stage, whose buffers the quarters of the next stage then overwrite.  One
+    // barrier per RN tiles rather than per tile: the wavefronts' tile times differ a lot (a list
+    // insertion now and then), and every barrier costs the slowest one's.  Past the end of the
+    // slice the last tile is loaded again; those copies are never read.
     //
-    // The tiles come through a ring of two stages of RN tiles.  Before the first tile of stage s
-    // is multiplied every wavefront waits for its own quarters of that stage (issued a whole
-    // stage earlier) and meets the others at the barrier; the barrier also says that everybody
-    // has multiplied the tiles of stage s-1, whose buffers the quarters of stage s+1 then
-    // overwrite.  One barrier per RN tiles rather than per tile: the wavefronts' tile times
-    // differ a lot (a list insertion now and then), and every barrier costs the slowest one's.
-    // Past the end of the slice the last tile is loaded (and multiplied) again; those copies and
-    // products are never used.
-    constexpr int kVmPerStage = RN * NP;
-    static_assert(kVmPerStage < 64, "vmcnt immediate");
-    constexpr int kWaitStage = 0x0F70 | (kVmPerStage & 15) | ((kVmPerStage >> 4) << 14);   // vmcnt(RN*NP)
-    constexpr int PARTS = 2 * KB;                  // 3 MFMAs each
-    constexpr int PPG = PARTS / 8;                 // parts per group of four scores
+    // The MFMAs of a tile are not overlapped with the selection of the previous one inside the
+    // wavefront: that costs 32 more registers, and at this size the third wavefront per SIMD that
+    // the registers buy instead hides more.
     floatx16 acc_a, acc_b;
-    // item fragments of k-block kb live in fh/fm[kb & 1] and are read one k-block (two groups of
-    // scores) ahead of their MFMAs, so that the LDS latency is not waited for
-    bf16x8 fh[2], fm[2];
+    // the item fragment of k-block kb lives in fi[kb & 1] and is read one k-block ahead of its
+    // MFMAs, so that the LDS latency is not waited for
+    half8 fi[2];
     auto load_frags = [&](int kb, const float *src) {
-      // chunk 2*kb + half of the high-part plane, swizzled in its low 4 bits.  The remainder
-      // plane lies D*2 bytes further: at D = 64 that is bit 3 of the (swizzled) chunk index, so
-      // the offset is applied by XOR; at D = 128 it is outside the swizzled bits
-      const uint32_t a_h = frag_off ^ (uint32_t)((2 * kb) * 16);
-      const uint32_t a_m = DC == 1 ? (a_h ^ 128u) : (a_h + 256u);
-      fh[kb & 1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a_h));
-      fm[kb & 1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a_m));
+      const uint32_t a = frag_off ^ (uint32_t)((2 * kb) * 16);
+      fi[kb & 1] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a));
     };
-    auto mfma_part = [&](int part, const float *src) {
-      const int kb = part >> 1, b = kb & 1;
-      if ((part & 1) == 0) {
-        if (part == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            acc_a[r] = 0.0f;
-            acc_b[r] = 0.0f;
-          }
-        }
-        if (kb + 1 < KB) load_frags(kb + 1, src);
-        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm[b], uha[FILTER ? kb : 0], acc_a, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm[b], uhb[FILTER ? kb : 0], acc_b, 0, 0, 0);
-        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uma[FILTER ? kb : 0], acc_a, 0, 0, 0);
-      } else {
-        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], umb[FILTER ? kb : 0], acc_b, 0, 0, 0);
-        acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uha[FILTER ? kb : 0], acc_a, 0, 0, 0);
-        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], uhb[FILTER ? kb : 0], acc_b, 0, 0, 0);
-      }
-    };
-    float lo[16], hi[16];
     auto issue_stage = [&](int32_t first, int half_idx) {
 #pragma unroll
       for (int j = 0; j < RN; ++j) issue_tile(min(first + j, t_hi - 1), ring[half_idx * RN + j]);
     };
-    // select tile t (scores in lo/hi) while tile t+1 (in nxt, k-block 0 already read) is multiplied
-    auto body = [&](int32_t t, const float *nxt) {
-      range_and_mask(t, lo, hi);
-      asm volatile("" : "+v"(frag_off));  // as for lane_off: hoisted addresses cost registers
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) mfma_part((2 * g) * PPG + j, nxt);
-        consider_lo(t, g, lo);
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) mfma_part((2 * g + 1) * PPG + j, nxt);
-        consider_hi(t, g, hi);
-      }
-    };
     // The user fragments and the mask cursor are global loads too: all of them have to be back
     // before the in-order counter is used to tell the stages apart.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    static_assert(RN >= 2, "the stage of tile t+2 is synchronised at the end of tile t");
-    if (t_lo < t_hi) {
-      issue_stage(t_lo, 0);
-      issue_stage(t_lo + RN, 1);
-      __builtin_amdgcn_s_waitcnt(kWaitStage);      // stage 0 is in
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      load_frags(0, ring[0]);
-#pragma unroll
-      for (int part = 0; part < PARTS; ++part) mfma_part(part, ring[0]);
-      load_frags(0, ring[1]);
-      swap_halves(acc_a, acc_b, lo, hi);
-    }
+    if (t_lo < t_hi) issue_stage(t_lo, 0);
     int half_idx = 0;
     for (int32_t tb = t_lo; tb < t_hi; tb += RN, half_idx ^= 1) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_stage(tb + RN, half_idx ^ 1);
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
         const int32_t t = tb + j;
         if (t >= t_hi) break;                      // uniform over the workgroup
-        body(t, j == RN - 1 ? ring[(half_idx ^ 1) * RN] : ring[half_idx * RN + j + 1]);
-        if (j == RN - 2) {                         // tile t+2 opens the next stage
-          __builtin_amdgcn_s_waitcnt(0x0F70);
-#ifndef RK_EXP_NOBAR
-          __builtin_amdgcn_s_barrier();
-#endif
-          asm volatile("" ::: "memory");
-#ifndef RK_EXP_NODMA
-          issue_stage(tb + 2 * RN, half_idx);
-#endif
+        const float *cur = ring[half_idx * RN + j];
+        asm volatile("" : "+v"(frag_off));         // as for lane_off: hoisted addresses cost registers
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc_a[r] = 0.0f;
+          acc_b[r] = 0.0f;
         }
-        load_frags(0, j + 2 < RN ? ring[half_idx * RN + j + 2] : ring[(half_idx ^ 1) * RN + j + 2 - RN]);
-        swap_halves(acc_a, acc_b, lo, hi);         // scores of tile t+1
+        load_frags(0, cur);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          if (kb + 1 < KB) load_frags(kb + 1, cur);
+          acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fi[kb & 1], uha[FILTER ? kb : 0], acc_a, 0, 0, 0);
+          acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(fi[kb & 1], uhb[FILTER ? kb : 0], acc_b, 0, 0, 0);
+        }
+        float lo[16], hi[16];
+        swap_halves(acc_a, acc_b, lo, hi);
+        range_and_mask(t, lo, hi);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          consider_lo(t, g, lo);
+          consider_hi(t, g, hi);
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
