@@ -287,12 +287,15 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * range), may be NULL.  Item ids written are local index + item_id_offset.
  * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 32).
  *
- * rk_score_topk_f32 returns exactly what rk_score_topk_exact_f32 returns, faster: for
- * K <= 28 and D = 64 or 128 it first ranks by 16-bit scores (each embedding split into
- * two bf16 numbers, three bf16 MFMA products), re-scores the K+4.. best candidates per
- * user with the exact chain, and runs the exact kernel only for users whose result that
- * procedure cannot certify (candidate filter scores within the filter's error bound of
- * the K-th exact score).  Both take the same workspace. */
+ * All three entry points return the same bits; they differ in how they get there.
+ * rk_score_topk_exact_f32 ranks every score on the exact kernel.
+ * rk_score_topk_filtered_f32 (K <= 28, D = 64 or 128; otherwise it is the exact one) first ranks
+ * by fp16 scores (both tables copied to fp16, one fp16 MFMA per 16 k), keeps the K+8 best per
+ * user, re-scores those candidates with the exact chain, and runs the exact kernel only for users
+ * whose result that procedure cannot certify (a candidate's fp16 score within the fp16 error bound
+ * of the K-th exact score: ties at the K-th place, non-finite embeddings).
+ * rk_score_topk_f32 picks between the two by size (the filter pays off from ~10^9 scores).
+ * All take the same workspace. */
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D,
                               int32_t K);
 int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb,
@@ -307,6 +310,13 @@ int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users,
                             int32_t K, int32_t item_id_offset, float *out_scores,
                             int32_t *out_ids, void *ws, size_t ws_bytes,
                             void *stream);
+int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users,
+                               const float *Iemb, int32_t n_items, int32_t D,
+                               const int32_t *mask_ptr,
+                               const int32_t *mask_items, int32_t K,
+                               int32_t item_id_offset, float *out_scores,
+                               int32_t *out_ids, void *ws, size_t ws_bytes,
+                               void *stream);
 /* Merge P candidate lists per user (each Kin long, in any order, P * Kin <= 1024;
  * padding entries have id < 0) into the best K by (score desc, id asc).  Used for
  * the item slices inside one GPU and for the per-GPU lists of a user slice after

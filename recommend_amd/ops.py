@@ -450,11 +450,16 @@ def modal_sum(feats, alphas):
 # --------------------------------------------------------------------------
 # E1 / M: evaluation
 # --------------------------------------------------------------------------
-def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0, exact_only=False):
+_TOPK_ENTRY = {"auto": "rk_score_topk_f32", "exact": "rk_score_topk_exact_f32",
+               "filter": "rk_score_topk_filtered_f32"}
+
+
+def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0, mode="auto"):
     """Top-K items per user of U @ I.T with masked pairs scored -1e10, without
     materialising the score matrix.  Returns (scores [U,K] fp32, ids [U,K] int32).
-    exact_only: skip the bf16 candidate filter and rank every score on the exact kernel
-    (same result, slower)."""
+    mode: "exact" ranks every score on the exact kernel; "filter" ranks fp16 scores first and
+    re-scores the candidates exactly (same result, faster on large problems); "auto" picks by
+    size."""
     _need_cuda(U, I, mask_ptr, mask_items)
     U, I = _f32c(U.detach()), _f32c(I.detach())
     if mask_items is None or mask_items.numel() == 0:
@@ -466,7 +471,7 @@ def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0, exact_
     ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=U.device)
     out_s = torch.empty((n_users, K), dtype=torch.float32, device=U.device)
     out_i = torch.empty((n_users, K), dtype=torch.int32, device=U.device)
-    _ffi.call("rk_score_topk_exact_f32" if exact_only else "rk_score_topk_f32",
+    _ffi.call(_TOPK_ENTRY[mode],
               ptr(U), c_int32(n_users), ptr(I), c_int32(n_items), c_int32(D),
               ptr(mask_ptr), ptr(mask_items), c_int32(K), c_int32(item_id_offset), ptr(out_s),
               ptr(out_i), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(U.device))

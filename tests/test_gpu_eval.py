@@ -78,7 +78,8 @@ def test_verifier_and_tester_vs_reference(golden, name):
 @pytest.mark.parametrize("U,I,D,K", [(1, 1, 64, 1), (5, 7, 64, 7), (129, 33, 64, 20), (300, 1000, 128, 32),
                                       (257, 4099, 64, 20), (1000, 257, 64, 5), (64, 20000, 64, 10),
                                       (2500, 400, 64, 20), (1500, 3000, 128, 10)])
-def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K):
+@pytest.mark.parametrize("mode", ["exact", "filter"])
+def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K, mode):
     """Quantised embeddings give many exactly equal scores: ids must come out in
     (score desc, id asc) order, identical to the oracle, for awkward shapes."""
     rng = np.random.default_rng(U * 7 + I)
@@ -90,12 +91,12 @@ def test_topk_exact_with_ties_and_ragged_shapes(U, I, D, K):
         rows = np.concatenate([rows[rows > 1], np.zeros(I, np.int64)])
         cols = np.concatenate([cols[:rows.shape[0] - I], np.arange(I)])
     ptr, mcols = pairs_to_csr(rows, cols, U)
-    s, ids = ops.score_topk(dev(ue), dev(ie), K, dev(ptr), dev(mcols))
+    s, ids = ops.score_topk(dev(ue), dev(ie), K, dev(ptr), dev(mcols), mode=mode)
     o_s, o_i = eval_oracle.score_topk(ue, ie, K, ptr, mcols)
     np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
     np.testing.assert_array_equal(s.cpu().numpy(), o_s)
     # no mask at all
-    s2, ids2 = ops.score_topk(dev(ue), dev(ie), K)
+    s2, ids2 = ops.score_topk(dev(ue), dev(ie), K, mode=mode)
     o_s2, o_i2 = eval_oracle.score_topk(ue, ie, K)
     np.testing.assert_array_equal(ids2.cpu().numpy(), o_i2)
     np.testing.assert_array_equal(s2.cpu().numpy(), o_s2)
@@ -115,8 +116,8 @@ def test_filtered_ranking_equals_exact_kernel(U, I, D, K, scale):
     rng = np.random.default_rng(I)
     ptr, mcols = pairs_to_csr(rng.integers(0, U, 20 * U), rng.integers(0, I, 20 * U), U)
     for off in (0, 12345):
-        fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off)
-        es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off, exact_only=True)
+        fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off, mode="filter")
+        es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), item_id_offset=off, mode="exact")
         assert torch.equal(fi, ei)
         assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
     o_s, o_i = eval_oracle.score_topk(ue[:64].cpu().numpy(), ie.cpu().numpy(), K, ptr[:65], mcols[:ptr[64]])
@@ -136,8 +137,8 @@ def test_filter_falls_back_when_nothing_can_be_certified(U):
     ue[::3] = torch.randn(U, D, generator=g).to(DEV)[::3]
     rng = np.random.default_rng(U)
     ptr, mcols = pairs_to_csr(rng.integers(0, U, 5 * U), rng.integers(0, I, 5 * U), U)
-    fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols))
-    es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), exact_only=True)
+    fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), mode="filter")
+    es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), mode="exact")
     assert torch.equal(fi, ei) and torch.equal(fs, es)
     o_s, o_i = eval_oracle.score_topk(ue.cpu().numpy(), ie.cpu().numpy(), K, ptr, mcols)
     np.testing.assert_array_equal(fi.cpu().numpy(), o_i)
@@ -145,8 +146,8 @@ def test_filter_falls_back_when_nothing_can_be_certified(U):
     ie2[5, 3] = float("inf")
     ie2[17, 0] = float("nan")
     ie2[40] = 3e38
-    fs, fi = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols))
-    es, ei = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols), exact_only=True)
+    fs, fi = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols), mode="filter")
+    es, ei = ops.score_topk(ue, ie2, K, dev(ptr), dev(mcols), mode="exact")
     assert torch.equal(fi, ei)
     assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
 

@@ -25,7 +25,7 @@ lib = _ffi.load()
 ws_bytes = lib.rk_score_topk_ws_bytes(d.n_users, d.n_items, a.dim, a.k)
 ws = torch.zeros(ws_bytes // 4 + 4, dtype=torch.float32, device=dev)
 out = {}
-for name in ("rk_score_topk_exact_f32", "rk_score_topk_f32"):
+for name in ("rk_score_topk_exact_f32", "rk_score_topk_filtered_f32"):
     os_ = torch.empty((d.n_users, a.k), dtype=torch.float32, device=dev)
     oi = torch.empty((d.n_users, a.k), dtype=torch.int32, device=dev)
     def run():
@@ -43,7 +43,7 @@ for name in ("rk_score_topk_exact_f32", "rk_score_topk_f32"):
 done_off = (ws_bytes - ((4 * d.n_users + 255) // 256) * 256) // 4
 done = ws[done_off:done_off + d.n_users].view(torch.int32)
 print("users left to the exact pass:", int((done == 0).sum()), "of", d.n_users)
-(es, ei), (fs, fi) = out["rk_score_topk_exact_f32"], out["rk_score_topk_f32"]
+(es, ei), (fs, fi) = out["rk_score_topk_exact_f32"], out["rk_score_topk_filtered_f32"]
 print("ids equal:", bool(torch.equal(ei, fi)), " scores bit-equal:", bool(torch.equal(es.view(torch.int32), fs.view(torch.int32))))
 if not torch.equal(ei, fi):
     bad = (ei != fi).any(1).nonzero().flatten()
