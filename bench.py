@@ -9,8 +9,9 @@ the whole job.  With N > 1 the item table is sharded over the ranks (per-GPU
 top-K, RCCL all-gather, merge): total work is fixed, so scaling is "strong".
 
 Also reported on the same JSON line: the SpMM hop (algorithmic GB/s against the
-HBM roofline, `roofline_spmm`), the fused top-K kernel against the fp32 MFMA
-roofline (`roofline`, the dominant kernel of the timed step), one full MMFCN
+HBM roofline, `roofline_spmm`), the fused top-K call against the MFMA roofline of
+its dominant kernel (`roofline`: the fp16 candidate filter at this size; the exact
+fp32 kernel beside it as `roofline_exact_kernel`), one full MMFCN
 training epoch timed step by step (`epoch`), and the CPU baseline (`cpu_baseline`,
 the oracle's reference-style evaluation on the host cores, rank 0, N = 1 only).
 """
@@ -42,8 +43,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 # Memory-side bytes per launch at the Elec shape from rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950
 # requires for 16-B-per-lane reads, plus WRITE_SIZE; one counter per run): profiles/r01_pmc_*.csv.
 # They are measurements of THIS shape on one GPU; other shapes report null.
-PMC_TRAFFIC_ELEC = {"score_topk": 2 * 363.0e6 + 72.2e6, "spmm": 2 * 252.3e6 + 63.9e6}
+PMC_TRAFFIC_ELEC = {"score_topk": 2 * 687.0e6 + 207.2e6, "spmm": 2 * 252.3e6 + 63.9e6}
 MFMA_F32_PEAK_TFS = 157.3    # MI355X fp32 matrix peak
+MFMA_F16_PEAK_TFS = 2500.0   # MI355X dense fp16 / bf16 matrix peak
 BATCH = {"baby": 2048, "clothing": 1024, "sports": 256, "elec": 256}   # reference config.py presets
 
 
@@ -214,18 +216,36 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     users_per_s = U * args.steps / elapsed
 
-    # dominant kernel of the step: fused score + mask + top-K (+ list merge), per launch
+    # dominant kernels of the step: the fused score + mask + top-K launch sequence.  At this size
+    # it is the fp16 candidate filter + exact re-scoring (results identical to the exact fp32
+    # kernel, which is timed beside it against its own, fp32-input MFMA peak).
     n_loc = I if world == 1 else (ev.hi - ev.lo)
     topk_fn = (lambda: ev.topk(ue, ie, 20)) if world == 1 else (lambda: ev.local_topk(ue, ie, 20))
     topk_fn()
     ms_topk = event_ms(topk_fn, max(3, args.steps))
-    tflops = 2.0 * U * n_loc * D / (ms_topk * 1e-3) / 1e12
-    roofline = {"kernel": "score_topk_kernel (+topk_merge_kernel)", "bound": "mfma", "achieved": round(tflops, 3),
-                "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFS, 4),
+    flop = 2.0 * U * n_loc * D
+    tflops = flop / (ms_topk * 1e-3) / 1e12
+    filtered = U * n_loc >= (1 << 30) and D in (64, 128)   # what rk_score_topk_f32 decides
+    peak = MFMA_F16_PEAK_TFS if filtered else MFMA_F32_PEAK_TFS
+    roofline = {"kernel": ("score_topk_kernel<fp16 filter> + merge + refine + exact fallback (one rk_score_topk_f32 call)"
+                           if filtered else "score_topk_kernel (+topk_merge_kernel)"),
+                "bound": "mfma", "achieved": round(tflops, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tflops / peak, 4),
                 "traffic": PMC_TRAFFIC_ELEC["score_topk"] if (args.shape == "elec" and world == 1 and D == 64) else None,
-                "traffic_unit": "B per launch (L2 memory-side requests, Infinity-Cache hits included)",
+                "traffic_unit": "B per call (L2 memory-side requests, Infinity-Cache hits included)",
                 "ms_per_launch": round(ms_topk, 4),
-                "algorithmic": f"2*U*I*D = {2.0 * U * n_loc * D:.4g} flop per launch"}
+                "algorithmic": f"2*U*I*D = {flop:.4g} flop per call",
+                "note": ("peak is the dense fp16 MFMA rate, the arithmetic of the dominant kernel; that kernel is bound "
+                         "by the vector instructions of the top-K selection, not by the matrix pipe" if filtered else "")}
+    roofline_exact = None
+    if world == 1:
+        exact_fn = lambda: ev.topk(ue, ie, 20, mode="exact")
+        exact_fn()
+        ms_exact = event_ms(exact_fn, max(3, args.steps))
+        tf_exact = flop / (ms_exact * 1e-3) / 1e12
+        roofline_exact = {"kernel": "score_topk_kernel<fp32> + topk_merge (rk_score_topk_exact_f32)", "bound": "mfma",
+                          "achieved": round(tf_exact, 3), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                          "frac": round(tf_exact / MFMA_F32_PEAK_TFS, 4), "ms_per_launch": round(ms_exact, 4)}
 
     # ---------------------------------------------------------------- SpMM hop
     h = torch.randn(N, D, device=dev)
@@ -308,12 +328,13 @@ def main():
             "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
             "value": round(users_per_s, 1), "unit": "users/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f32 (results; candidates by fp16 MFMA, certified against the fp32 chain)",
             "data": "synthetic",
             "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
                                    f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
                        "parallelism": "single GPU" if world == 1 else f"items sharded over {world} GPUs, all-gather + merge"},
-            "roofline": roofline, "roofline_spmm": roofline_spmm,
+            "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
             "spmm_transpose_ms": round(ms_spmm_t, 5),
             "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
             "recall@20": round(float(res["recall@20"]), 6),

@@ -1,4 +1,4 @@
-// Shared by eval.hip (exact fp32 scores) and eval_filter.hip (bf16 x 2 filter scores): the fused
+// Shared by eval.hip (exact fp32 scores) and eval_filter.hip (fp16 filter scores): the fused
 // score + mask + top-K kernel.  See eval.hip for the description of the kernel.
 #pragma once
 #include "common.h"

@@ -87,13 +87,13 @@ class RankingEvaluator:
             self._dev[device] = st
         return st
 
-    def topk(self, user_embeddings, item_embeddings, k):
-        """Ranked top-k item ids per user with the training pairs masked."""
+    def topk(self, user_embeddings, item_embeddings, k, mode="auto"):
+        """Ranked top-k item ids per user with the training pairs masked (mode: ops.score_topk)."""
         st = self._device_state(user_embeddings.device)
         U, I = _pad64(user_embeddings), _pad64(item_embeddings)
         has_mask = st["mask_items"].numel() > 0
         return ops.score_topk(U, I, k, st["mask_ptr"] if has_mask else None,
-                              st["mask_items"] if has_mask else None)
+                              st["mask_items"] if has_mask else None, mode=mode)
 
     def evaluate(self, user_embeddings, item_embeddings) -> Dict[str, torch.Tensor]:
         n_items = item_embeddings.shape[0]
