@@ -152,6 +152,33 @@ def test_filter_falls_back_when_nothing_can_be_certified(U):
     assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_filtered_equals_exact_on_random_configurations(seed):
+    """Random shapes, K, embedding magnitudes (down to fp16-subnormal products and up to values far
+    beyond the fp16 range: the per-row / per-table power-of-two scaling), mask densities, duplicate
+    rows (exact ties) and sparse rows: the filtered path returns the exact kernel's bits."""
+    rng = np.random.default_rng(1000 + seed)
+    U = int(rng.integers(1, 700))
+    I = int(rng.integers(1, 3000))
+    D = int(rng.choice([64, 128]))
+    K = int(rng.integers(1, min(I, 28) + 1))
+    su, si = 10.0 ** rng.uniform(-18, 12), 10.0 ** rng.uniform(-18, 12)
+    ue = (rng.standard_normal((U, D)) * su).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * si).astype(np.float32)
+    ue *= (10.0 ** rng.uniform(-3, 3, size=(U, 1))).astype(np.float32)       # users of very different norms
+    if I > 4:
+        ie[rng.integers(0, I, I // 4)] = ie[rng.integers(0, I, I // 4)]       # duplicate items: exact ties
+        ie[rng.integers(0, I, max(1, I // 10))] *= np.float32(rng.choice([0.0, 1e-4, 50.0]))
+    ie[:, rng.integers(0, D, D // 3)] = 0.0
+    n_mask = int(rng.integers(0, 30 * U + 1))
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, n_mask), rng.integers(0, I, n_mask), U)
+    mp, mc = (dev(ptr), dev(mcols)) if n_mask else (None, None)
+    fs, fi = ops.score_topk(dev(ue), dev(ie), K, mp, mc, mode="filter")
+    es, ei = ops.score_topk(dev(ue), dev(ie), K, mp, mc, mode="exact")
+    assert torch.equal(fi, ei), (U, I, D, K, su, si)
+    assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+
+
 def test_item_offset_and_merge_equal_unsharded():
     """Two item shards ranked separately and merged give the unsharded ranking."""
     rng = np.random.default_rng(4)
