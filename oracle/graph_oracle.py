@@ -109,3 +109,52 @@ def agg_func(src, dst, w, node_x, k, f):
         h = f(h)
         h = spmm(src, dst, w, h)
     return h
+
+
+# ---- live-model variants of the propagation primitive (dropout off: eval mode) ----
+def mgdcf_gamma(alpha, beta, k):
+    """model/mig/mgdcf.py:46-48."""
+    return np.power(beta, k) + alpha * np.sum([np.power(beta, i) for i in range(k)])
+
+
+def mgdcf_sorted_homo_edges(user_index, item_index, num_users, num_items):
+    """model/mig/mgdcf.py:78-96: u->i edges, i->u edges, then one self loop per node."""
+    n = num_users + num_items
+    hi = np.asarray(item_index) + num_users
+    ui = np.asarray(user_index)
+    loops = np.arange(n)
+    return np.concatenate([ui, hi, loops]), np.concatenate([hi, ui, loops]), n
+
+
+def mgdcf_forward(src, dst, w, x, k, alpha, beta, return_all=False):
+    """model/mig/mgdcf.py:131-166 with the three dropouts inactive."""
+    h0 = x.astype(np.float32)
+    h = h0
+    hs = []
+    for _ in range(k):
+        h = spmm(src, dst, w, h)
+        h = (h * np.float32(beta) + h0 * np.float32(alpha)).astype(np.float32)
+        hs.append(h)
+    if not return_all:
+        return (h / np.float32(mgdcf_gamma(alpha, beta, k))).astype(np.float32)
+    return [(hh / np.float32(mgdcf_gamma(alpha, beta, i + 1))).astype(np.float32) for i, hh in enumerate(hs)]
+
+
+def ii_gcn_forward(src, dst, w, x, k, alpha, beta):
+    """model/sgrec/gcn.py:32-50 (II_GCN), dropouts inactive: every hop divides by gamma."""
+    gamma = np.float32(pow(beta, k) + alpha * sum(pow(beta, i) for i in range(k)))
+    h0 = x.astype(np.float32)
+    h = h0
+    for _ in range(k):
+        h = spmm(src, dst, w, h)
+        h = (h * np.float32(beta) + h0 * np.float32(alpha)).astype(np.float32)
+        h = (h / gamma).astype(np.float32)
+    return h
+
+
+def iu_gcn_forward(src, dst, w, x, k):
+    """model/sgrec/gcn.py:74-87 (IU_GCN), dropouts inactive: k plain hops."""
+    h = x.astype(np.float32)
+    for _ in range(k):
+        h = spmm(src, dst, w, h)
+    return h

@@ -113,6 +113,14 @@ class CsrMatrix:
         _ffi.call("rk_gather_f32", ptr(w_coo), ptr(self.eid), c_int64(self.nnz), ptr(self.val),
                   stream_ptr(self.device))
 
+    def with_values(self, w_coo):
+        """The same sparsity pattern with its own edge values (e.g. one draw of edge dropout):
+        shares the index arrays and the row binning, owns `val`."""
+        import copy
+        m = copy.copy(self)
+        m.set_values_from_coo(w_coo)
+        return m
+
     def plan(self, D):
         if not self.n_chunks:
             return None, None

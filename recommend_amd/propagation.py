@@ -1,0 +1,130 @@
+"""The propagation layers of the reference's live model families on the HIP SpMM.
+
+Mirrors, with the same class names, constructor arguments and forward signatures:
+  MGDCF   model/mig/mgdcf.py:14-175   h <- beta * A h + alpha * h0, k times, / gamma
+  II_GCN  model/sgrec/gcn.py:7-50     the same with / gamma and z-dropout after every hop
+  IU_GCN  model/sgrec/gcn.py:55-87    k plain hops with z-dropout after each
+The graph argument `g` is a DeviceGraph (graph_constructor.py) instead of a DGLGraph: the
+COO edge list in the reference's order plus CSR/CSC operands in HBM; `g.edata[key]` holds
+edge values in COO order as it does in DGL.  Every hop -- forward and backward -- is one
+rk_spmm_csr_f32 launch with the alpha/beta epilogue fused; the three nn.Dropout modules of
+the reference are kept as they are (edge dropout acts on the COO value vector, from which
+both operands of that forward pass take their values).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .graph_constructor import DeviceGraph
+
+
+def _operands(g: DeviceGraph, key, edge_dropout: nn.Dropout):
+    """CSR/CSC operands carrying edata[key], after edge dropout when it is active."""
+    if g.fwd is None:
+        g.to("cuda")
+    w = g.edata[key]
+    if edge_dropout.training and edge_dropout.p > 0:
+        w = edge_dropout(w)
+        return g.fwd.with_values(w), g.bwd.with_values(w)
+    g.refresh_values(key)
+    return g.fwd, g.bwd
+
+
+class MGDCF(nn.Module):
+
+    CACHE_KEY = "mgdcf_weight"
+
+    def __init__(self, k, alpha, beta, x_drop_rate, edge_drop_rate, z_drop_rate, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.k = k
+        self.alpha = alpha
+        self.beta = beta
+        self.gamma = torch.tensor(MGDCF.compute_gamma(alpha, beta, k)).float()
+        self.gammas = [torch.tensor(MGDCF.compute_gamma(alpha, beta, i)).float() for i in range(1, k + 1)]
+        self.x_drop_rate = x_drop_rate
+        self.edge_drop_rate = edge_drop_rate
+        self.z_drop_rate = z_drop_rate
+        self.x_dropout = nn.Dropout(x_drop_rate)
+        self.edge_dropout = nn.Dropout(edge_drop_rate)
+        self.z_dropout = nn.Dropout(z_drop_rate)
+
+    @classmethod
+    def compute_gamma(cls, alpha, beta, k):
+        return np.power(beta, k) + alpha * np.sum([np.power(beta, i) for i in range(k)])
+
+    @classmethod
+    def build_sorted_homo_graph(cls, user_item_edges, num_users=None, num_items=None):
+        """mgdcf.py:78-104: edges u->i, then i->u, then one self loop per node, unit weights."""
+        user_index, item_index = np.asarray(user_item_edges).T
+        if num_users is None:
+            num_users = int(np.max(user_index)) + 1
+        if num_items is None:
+            num_items = int(np.max(item_index)) + 1
+        n = num_users + num_items
+        homo_item = item_index.astype(np.int64) + num_users
+        loops = np.arange(n, dtype=np.int64)
+        src = np.concatenate([user_index.astype(np.int64), homo_item, loops]).astype(np.int32)
+        dst = np.concatenate([homo_item, user_index.astype(np.int64), loops]).astype(np.int32)
+        return DeviceGraph(src, dst, np.ones(src.shape[0], np.float32), n)
+
+    @classmethod
+    @torch.no_grad()
+    def norm_adj(cls, g):
+        """mgdcf.py:107-128: w_e = in_deg[src]^-0.5 * in_deg[dst]^-0.5."""
+        if g.fwd is None:
+            g.to("cuda")
+        g.edata[MGDCF.CACHE_KEY] = ops.deg_normalize(g.fwd)
+
+    def forward(self, g, x, return_all=False):
+        fwd, bwd = _operands(g, MGDCF.CACHE_KEY, self.edge_dropout)
+        h0 = self.x_dropout(x)
+        h = h0
+        h_list = []
+        for _ in range(self.k):
+            h = ops.spmm(fwd, bwd, h, h0, self.alpha, self.beta)   # h * beta + h0 * alpha, fused
+            if return_all:
+                h_list.append(h)
+        if not return_all:
+            return self.z_dropout(h / self.gamma.to(h.device))
+        return [self.z_dropout(hh / gamma.to(hh.device)) for hh, gamma in zip(h_list, self.gammas)]
+
+
+class II_GCN(nn.Module):
+    def __init__(self, k, alpha, beta, edge_drop_rate, x_drop_rate, z_drop_rate, cache_key):
+        super().__init__()
+        self.k = k
+        self.beta = beta
+        self.alpha = alpha
+        self.gamma = pow(self.beta, k) + self.alpha * sum(pow(self.beta, i) for i in range(k))
+        self.x_dropout = nn.Dropout(x_drop_rate)
+        self.edge_dropout = nn.Dropout(edge_drop_rate)
+        self.z_dropout = nn.Dropout(z_drop_rate)
+        self.cache_key = cache_key
+
+    def forward(self, x, g):
+        fwd, bwd = _operands(g, self.cache_key, self.edge_dropout)
+        h0 = self.x_dropout(x)
+        h = h0
+        for _ in range(self.k):
+            # (h * beta + h0 * alpha) / gamma with the division folded into the coefficients
+            h = ops.spmm(fwd, bwd, h, h0, self.alpha / self.gamma, self.beta / self.gamma)
+            h = self.z_dropout(h)
+        return h
+
+
+class IU_GCN(nn.Module):
+    def __init__(self, edge_drop_rate, x_drop_rate, z_drop_rate, cache_key):
+        super().__init__()
+        self.x_dropout = nn.Dropout(x_drop_rate)
+        self.edge_dropout = nn.Dropout(edge_drop_rate)
+        self.z_dropout = nn.Dropout(z_drop_rate)
+        self.cache_key = cache_key
+
+    def forward(self, x, g, k):
+        self.k = k
+        fwd, bwd = _operands(g, self.cache_key, self.edge_dropout)
+        h = self.x_dropout(x)
+        for _ in range(k):
+            h = self.z_dropout(ops.spmm(fwd, bwd, h))
+        return h

@@ -193,3 +193,35 @@ def test_loss_variant_oracles_match_reference(golden):
             outputs = {"user_embeddings": ue, "item_embeddings": ie, "id_embeddings": torch.cat([ue, ie]), "pres": ue}
             got = float(loss_oracle.mmgcn_loss(outputs, {"user_ids": users, "item_ids": pos, "neg_items": neg}))
             assert abs(got - float(z[f"{name}/mmgcn_loss"])) <= 1e-6 * abs(float(z[f"{name}/mmgcn_loss"]))
+
+
+def test_propagation_variant_oracles_against_dense_fp64():
+    """The restatements of MGDCF / II_GCN / IU_GCN agree with a dense float64 evaluation of the
+    same recurrences (parity unpinned with respect to DGL, which is not installed)."""
+    import numpy as np
+    from oracle import graph_oracle
+    rng = np.random.default_rng(0)
+    U, I = 30, 20
+    pairs = np.unique(np.stack([rng.integers(0, U, 150), rng.integers(0, I, 150)], 1), axis=0)
+    src, dst, n = graph_oracle.mgdcf_sorted_homo_edges(pairs[:, 0], pairs[:, 1], U, I)
+    assert src.shape[0] == 2 * pairs.shape[0] + n
+    w = graph_oracle.deg_normalize(src, dst, n)
+    A = np.zeros((n, n))
+    np.add.at(A, (dst, src), w.astype(np.float64))
+    assert np.allclose(A, A.T)                      # symmetric normalisation of a symmetric graph
+    x = rng.standard_normal((n, 8)).astype(np.float32)
+    k, alpha, beta = 3, 0.1, 0.9
+    h, hs = x.astype(np.float64), []
+    for _ in range(k):
+        h = beta * (A @ h) + alpha * x
+        hs.append(h)
+    gam = [graph_oracle.mgdcf_gamma(alpha, beta, i + 1) for i in range(k)]
+    assert abs(gam[0] - (beta + alpha)) < 1e-12
+    np.testing.assert_allclose(graph_oracle.mgdcf_forward(src, dst, w, x, k, alpha, beta), hs[-1] / gam[-1], rtol=1e-5, atol=1e-6)
+    for got, want, g_ in zip(graph_oracle.mgdcf_forward(src, dst, w, x, k, alpha, beta, True), hs, gam):
+        np.testing.assert_allclose(got, want / g_, rtol=1e-5, atol=1e-6)
+    h = x.astype(np.float64)
+    for _ in range(k):
+        h = (beta * (A @ h) + alpha * x) / gam[-1]
+    np.testing.assert_allclose(graph_oracle.ii_gcn_forward(src, dst, w, x, k, alpha, beta), h, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(graph_oracle.iu_gcn_forward(src, dst, w, x, 2), A @ (A @ x), rtol=1e-5, atol=1e-6)
