@@ -158,3 +158,19 @@ def iu_gcn_forward(src, dst, w, x, k):
     for _ in range(k):
         h = spmm(src, dst, w, h)
     return h
+
+
+def build_item_graph(feat, k):
+    """model/sgrec/graph.py:100-118 densely in float64 (argsort instead of torch.topk: ties go to
+    the lower id).  Returns (src, dst, w) in score.nonzero() order."""
+    f = feat.astype(np.float64)
+    nf = f / np.sqrt((f ** 2).sum(1, keepdims=True))
+    score = nf @ nf.T
+    n = score.shape[0]
+    idx = np.argsort(-score, axis=1, kind="stable")[:, :k]
+    mask = np.zeros_like(score, dtype=bool)
+    mask[np.arange(n)[:, None], idx] = True
+    score = score * mask
+    score = (1.0 / (score.sum(1) + 1e-8))[:, None] * score
+    dst, src = np.nonzero(score)
+    return src, dst, score[dst, src]

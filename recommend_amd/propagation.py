@@ -128,3 +128,39 @@ class IU_GCN(nn.Module):
         for _ in range(k):
             h = self.z_dropout(ops.spmm(fwd, bwd, h))
         return h
+
+
+def build_item_graph(feat: torch.Tensor, k: int, weight_key: str, chunk_rows: int = 8192) -> DeviceGraph:
+    """Item-item kNN graph of model/sgrec/graph.py:100-118 (build_item_g) without the dense
+    I x I matrices: cosine similarities of one block of rows at a time (a library GEMM), the k
+    largest of each row by rk_rows_topk_f32 (ties: lower item id), weights s / (sum of the
+    row's k similarities + 1e-8).  Edges run from the neighbour (src) to the row item (dst),
+    ordered by (dst, src) as score.nonzero() lists them; exact-zero similarities are dropped
+    as nonzero() drops them.  feat: [I, F] on the GPU.  Returns the graph with
+    edata[weight_key] set."""
+    if not feat.is_cuda:
+        from . import _ffi
+        raise _ffi.RkError(_ffi.RK_ERR_NODEV, "build_item_graph: features must be on the GPU")
+    if not 1 <= k <= min(32, feat.shape[0]):
+        raise ValueError("k must be in the range [1, min(32, num_items)]")
+    feat = feat.float()
+    nf = feat / torch.sqrt(torch.sum(feat ** 2, dim=1, keepdim=True))
+    n = nf.shape[0]
+    src_parts, dst_parts, w_parts = [], [], []
+    for b in range(0, n, chunk_rows):
+        score = nf[b:b + chunk_rows] @ nf.T
+        vals, ids = ops.rows_topk(score, k)
+        inv = 1.0 / (vals.sum(dim=1, keepdim=True) + 1e-8)
+        w = inv * vals
+        order = torch.argsort(ids, dim=1)                  # nonzero() order: ascending column
+        ids, w = torch.gather(ids, 1, order), torch.gather(w, 1, order)
+        rows = torch.arange(b, b + ids.shape[0], device=feat.device, dtype=torch.int32).unsqueeze(1).expand_as(ids)
+        keep = w != 0
+        src_parts.append(ids[keep]), dst_parts.append(rows[keep]), w_parts.append(w[keep])
+    src = torch.cat(src_parts).cpu().numpy().astype(np.int32)
+    dst = torch.cat(dst_parts).cpu().numpy().astype(np.int32)
+    w = torch.cat(w_parts).float()
+    g = DeviceGraph(src, dst, w.cpu().numpy(), n)
+    g.to(feat.device)
+    g.edata[weight_key] = w
+    return g

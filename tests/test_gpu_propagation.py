@@ -101,3 +101,19 @@ def test_training_mode_dropouts_are_consistent_between_forward_and_backward():
         acc += layer2(g, x)
     ref = layer2.eval()(g, x)
     assert float((acc / 64 - ref).abs().mean()) < 0.2 * float(ref.abs().mean())
+
+
+def test_item_knn_graph_vs_dense_oracle():
+    rng = np.random.default_rng(9)
+    feat = rng.standard_normal((700, 384)).astype(np.float32)
+    from recommend_amd.propagation import build_item_graph
+    g = build_item_graph(torch.from_numpy(feat).to(DEV), 10, "ii_weight", chunk_rows=256)
+    src, dst, w = graph_oracle.build_item_graph(feat, 10)
+    np.testing.assert_array_equal(g.src, src)
+    np.testing.assert_array_equal(g.dst, dst)
+    np.testing.assert_allclose(g.edata["ii_weight"].cpu().numpy(), w, rtol=2e-5)
+    assert g.num_edges() == 700 * 10
+    # rows sum to one; the graph feeds the item-item layer
+    x = torch.randn(700, 64, device=DEV)
+    out = II_GCN(2, 0.1, 0.9, 0.0, 0.0, 0.0, "ii_weight").eval()(x, g)
+    _close(out.cpu().numpy(), graph_oracle.ii_gcn_forward(src, dst, w.astype(np.float32), x.cpu().numpy(), 2, 0.1, 0.9))
