@@ -241,6 +241,13 @@ int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_u
 
 }  // namespace
 
+#ifdef RK_STAMP
+extern "C" int rk_debug_stamps(unsigned long long *out, int reset) {
+  if (reset) { unsigned long long z[8] = {0,0,0,0,0,0,0,0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long));
+}
+#endif
+
 namespace rk {
 
 int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *out, float *norms,

@@ -107,6 +107,18 @@ struct LaneList {
 //   user_list != NULL: position p < *user_count stands for user user_list[p] (row of Uemb and of
 //     the mask); part_* rows are positions; nothing runs if *user_count > gate_cap.  n_users is
 //     then the number of positions the grid covers.
+#ifdef RK_STAMP
+__device__ inline int n_tiles_stamp(int a, int b) { return b - a; }
+// Diagnostic build: cycles of wavefront lifetime per phase of the filter loop, summed over all
+// wavefronts (s_memtime around the phases; the stamps themselves cost about a tenth).
+__device__ unsigned long long g_stamp[8];
+#define RK_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RK_ACC(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define RK_T(var)
+#define RK_ACC(i, a, b)
+#endif
+
 template <int KPAD, int DC, bool FILTER>
 __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_kernel(
     const float *__restrict__ Uemb, int32_t n_users,
@@ -429,17 +441,26 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (t_lo < t_hi) issue_stage(t_lo, 0);
     int half_idx = 0;
+#ifdef RK_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int32_t tb = t_lo; tb < t_hi; tb += RN, half_idx ^= 1) {
+      RK_T(s0);
       __builtin_amdgcn_s_waitcnt(0x0F70);
+      RK_T(s1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      RK_T(s2);
       issue_stage(tb + RN, half_idx ^ 1);
+      RK_T(s3);
+      RK_ACC(0, s0, s1); RK_ACC(1, s1, s2); RK_ACC(2, s2, s3);
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
         const int32_t t = tb + j;
         if (t >= t_hi) break;                      // uniform over the workgroup
         const float *cur = ring[half_idx * RN + j];
         asm volatile("" : "+v"(frag_off));         // as for lane_off: hoisted addresses cost registers
+        RK_T(p0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           acc_a[r] = 0.0f;
@@ -454,15 +475,32 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
         }
         float lo[16], hi[16];
         swap_halves(acc_a, acc_b, lo, hi);
+#ifdef RK_STAMP
+        asm volatile("" : "+v"(lo[0]), "+v"(hi[15]));
+#endif
+        RK_T(p1);
         range_and_mask(t, lo, hi);
+#ifdef RK_STAMP
+        asm volatile("" : "+v"(lo[0]), "+v"(hi[15]));
+#endif
+        RK_T(p2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           consider_lo(t, g, lo);
           consider_hi(t, g, hi);
         }
+        RK_T(p3);
+        RK_ACC(3, p0, p1); RK_ACC(4, p1, p2); RK_ACC(5, p2, p3);
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef RK_STAMP
+    if (lane == 0) {
+      for (int i = 0; i < 6; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+      atomicAdd(&g_stamp[6], (unsigned long long)n_tiles_stamp(t_lo, t_hi));
+      atomicAdd(&g_stamp[7], 1ull);
+    }
+#endif
   } else {
     // one tile: score and select from `cur`, the next tile on its way into `nxt`
     auto process_tile = [&](int32_t t, const float *cur, float *nxt) {

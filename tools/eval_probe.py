@@ -10,11 +10,13 @@ from recommend_amd.evaluator import pairs_to_csr
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="elec"); ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--k", type=int, default=20); ap.add_argument("--dim", type=int, default=64)
-ap.add_argument("--scale", type=float, default=0.1); ap.add_argument("--nomask", action="store_true")
+ap.add_argument("--scale", type=float, default=0.1); ap.add_argument("--nomask", action="store_true"); ap.add_argument("--users", type=int, default=0)
 a = ap.parse_args()
 d = synth.make_named(a.shape)
 tu, ti, _ = d.split(0)
 ptr, cols = pairs_to_csr(tu, ti, d.n_users)
+if a.users:
+    d.n_users = a.users; ptr = ptr[:a.users + 1]; cols = cols[:ptr[-1]]
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 ue = (torch.randn(d.n_users, a.dim, generator=g) * a.scale).to(dev)
