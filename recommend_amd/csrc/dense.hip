@@ -497,15 +497,32 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
     out[DD * DD + tid] = ((red_b[0][tid] + red_b[1][tid]) + red_b[2][tid]) + red_b[3][tid];
 }
 
-// last step of the partial reduction: adds the segment sums and routes them to dW / db / dalpha
+// Sum of the per-workgroup partials in a fixed order, routed to dW / db / dalpha: 16 lanes per
+// element stride the partials (two accumulators each) and are folded through LDS in lane order.
+// One launch: the partials (<= 512 x 17 KB, just written) come out of L2, and a second launch
+// would cost more than the whole reduction.
 constexpr int NRED = DD * DD + DD + 1;
-__global__ __launch_bounds__(256) void dense_route_kernel(const float *__restrict__ tmp, int32_t n_seg,
-                                                          float *__restrict__ dW, float *__restrict__ db,
-                                                          float *__restrict__ dalpha) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= NRED) return;
+__global__ __launch_bounds__(256) void dense_reduce_kernel(const float *__restrict__ slab, int32_t n_part,
+                                                           float *__restrict__ dW, float *__restrict__ db,
+                                                           float *__restrict__ dalpha) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (i < NRED) {
+    int32_t p = q;
+    for (; p + 16 < n_part; p += 32) {
+      s0 += slab[(int64_t)p * PART + i];
+      s1 += slab[(int64_t)(p + 16) * PART + i];
+    }
+    if (p < n_part) s0 += slab[(int64_t)p * PART + i];
+  }
+  red[q][el] = s0 + s1;
+  __syncthreads();
+  if (q != 0 || i >= NRED) return;
   float s = 0.0f;
-  for (int32_t k = 0; k < n_seg; ++k) s += tmp[(int64_t)k * NRED + i];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][el];
   if (i < DD * DD)
     dW[i] = s;
   else if (i < DD * DD + DD) {
@@ -599,13 +616,8 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
   else
     dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
   RK_CHECK_LAUNCH("dense_bwd_kernel");
-  float *tmp = (float *)ws + (size_t)grid * PART;
-  const int n_seg = rk::slab_segments(grid);
-  dim3 rgrid((unsigned)rk::ceil_div(NRED, 64), (unsigned)n_seg);
-  rk::slab_reduce_stage1<<<rgrid, 256, 0, st>>>((const float *)ws, grid, PART, NRED, n_seg, tmp);
-  RK_CHECK_LAUNCH("slab_reduce_stage1");
-  dense_route_kernel<<<(NRED + 255) / 256, 256, 0, st>>>(tmp, n_seg, dW, db, dalpha);
-  RK_CHECK_LAUNCH("dense_route_kernel");
+  dense_reduce_kernel<<<(NRED + 15) / 16, 256, 0, st>>>((const float *)ws, grid, dW, db, dalpha);
+  RK_CHECK_LAUNCH("dense_reduce_kernel");
   return RK_OK;
 }
 
