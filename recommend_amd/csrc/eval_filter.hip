@@ -243,8 +243,8 @@ int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_u
 
 #ifdef RK_STAMP
 extern "C" int rk_debug_stamps(unsigned long long *out, int reset) {
-  if (reset) { unsigned long long z[8] = {0,0,0,0,0,0,0,0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[10] = {0,0,0,0,0,0,0,0,0,0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), 10 * sizeof(unsigned long long));
 }
 #endif
 

@@ -111,7 +111,7 @@ struct LaneList {
 __device__ inline int n_tiles_stamp(int a, int b) { return b - a; }
 // Diagnostic build: cycles of wavefront lifetime per phase of the filter loop, summed over all
 // wavefronts (s_memtime around the phases; the stamps themselves cost about a tenth).
-__device__ unsigned long long g_stamp[8];
+__device__ unsigned long long g_stamp[10];
 #define RK_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define RK_ACC(i, a, b) st_acc[i] += (b) - (a)
 #else
@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
   int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
   int32_t next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
 
+#ifdef RK_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   LaneList<KPAD> list;
   list.init();
   float thr = -INFINITY;
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     // Bottom-tested with a single exit (an empty first round inserts -inf, a no-op): any other
     // shape makes the loop carry part of the list in two sets of registers, with a copy per entry
     // and round.
+    RK_T(f0);
     int q = 0;
 #pragma unroll 1
     do {
@@ -328,6 +332,8 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     } while (__any(q < qc));
     qc = 0;
     thr = list.s[KPAD - 1];
+    RK_T(f1);
+    RK_ACC(6, f0, f1);
   };
   // Four scores of this lane's user (ascending item ids).  Late in the stream hardly any score
   // beats its lane's threshold, so the wavefront first asks whether any lane has a candidate at
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v0), "v"(v1), "v"(v2));
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v3));
     if (!__any(m > thr)) return;
+    RK_T(c0);
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
       qc += v[i] > thr ? 1 : 0;
     }
     // a queue holds QS entries: insert when some lane could overflow within the next 4 scores
+    RK_T(c1);
+    RK_ACC(7, c0, c1);
     if (__any(qc > QS - 4)) flush();
   };
 
@@ -441,9 +450,6 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (t_lo < t_hi) issue_stage(t_lo, 0);
     int half_idx = 0;
-#ifdef RK_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (int32_t tb = t_lo; tb < t_hi; tb += RN, half_idx ^= 1) {
       RK_T(s0);
       __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #ifdef RK_STAMP
     if (lane == 0) {
-      for (int i = 0; i < 6; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
-      atomicAdd(&g_stamp[6], (unsigned long long)n_tiles_stamp(t_lo, t_hi));
-      atomicAdd(&g_stamp[7], 1ull);
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+      atomicAdd(&g_stamp[8], (unsigned long long)n_tiles_stamp(t_lo, t_hi));
+      atomicAdd(&g_stamp[9], 1ull);
     }
 #endif
   } else {

@@ -16,12 +16,12 @@ mp, mc = torch.from_numpy(ptr).cuda(), torch.from_numpy(cols).cuda()
 lib = _ffi.load()
 lib.rk_debug_stamps.restype = ctypes.c_int
 ops.score_topk(ue, ie, 20, mp, mc, mode="filter"); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 10)()
 lib.rk_debug_stamps(buf, 1)
 ops.score_topk(ue, ie, 20, mp, mc, mode="filter"); torch.cuda.synchronize()
 lib.rk_debug_stamps(buf, 0)
 v = list(buf)
-tiles, waves = v[6], v[7]
+tiles, waves = v[8], v[9]
 names = ["vmcnt(0) wait", "barrier", "DMA issue", "zero+frags+MFMA+swap", "range+mask", "selection"]
 print(f"wavefronts {waves}, wave-tiles {tiles}")
 for n, c in zip(names[:3], v[:3]):
@@ -29,3 +29,4 @@ for n, c in zip(names[:3], v[:3]):
 for n, c in zip(names[3:], v[3:6]):
     print(f"  {n:24s} {c / tiles:9.1f} cycles per wave-tile")
 print(f"  total                    {sum(v[:6]) / tiles:9.1f}")
+print(f"  of the selection: parking candidates {v[7] / tiles:9.1f}, sorted insertion (flush) {v[6] / tiles:9.1f}, gates and the rest {(v[5] - v[6] - v[7]) / tiles:9.1f}")
