@@ -118,16 +118,15 @@ __global__ __launch_bounds__(256) void to_half_rows_kernel(const float *__restri
   if (row >= n_rows) return;
   const int e = scale_exponent(row_maxabs ? row_maxabs[row] : table_stats[1]);
   if (row_exp && seg == 0) row_exp[row] = e;
-  const float sc = ldexpf(1.0f, -e);   // e in [-148, 128]: exact, possibly subnormal
   const float4 a = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg);
   const float4 b = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg + 4);
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   uint32_t w[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    // (two multiplications by powers of two when the scale itself would overflow fp32)
-    const float x0 = e > 126 ? v[2 * j] * 0.5f * ldexpf(1.0f, 1 - e) : v[2 * j] * sc;
-    const float x1 = e > 126 ? v[2 * j + 1] * 0.5f * ldexpf(1.0f, 1 - e) : v[2 * j + 1] * sc;
+    // ldexp on the value, not a multiplication by 2^-e: e runs from -148 (subnormal rows) to 128,
+    // where the factor itself is not an fp32 number; the result, at most 1 in magnitude, always is
+    const float x0 = ldexpf(v[2 * j], -e), x1 = ldexpf(v[2 * j + 1], -e);
     w[j] = (uint32_t)__half_as_ushort(__float2half_rn(x0)) | ((uint32_t)__half_as_ushort(__float2half_rn(x1)) << 16);
   }
   *reinterpret_cast<uint4 *>(out + row * D + 8 * seg) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -210,7 +209,9 @@ __global__ __launch_bounds__(256) void refine_kernel(
     // the two groups with a margin.  Non-finite embeddings make a norm, hence eps, infinite or NaN:
     // nothing is certified then and the exact kernel ranks everyone.
     const float eps = 1.25f * 0x1p-10f * unorm[user] * istats[0] + (float)D * 0x1p-22f * back + 1e-30f;
-    const bool ok = kc >= n_items || n_valid < kc || a_min + eps < tau;
+    // Every candidate slot must be filled (kc is at most n_items here): a filter score that is
+    // NaN never ranks, and a user with such scores has to be ranked by the exact kernel.
+    const bool ok = n_valid == kc && (kc >= n_items || a_min + eps < tau);
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
       const int32_t pos = atomicAdd(open_count, 1);

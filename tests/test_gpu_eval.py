@@ -179,6 +179,26 @@ def test_filtered_equals_exact_on_random_configurations(seed):
     assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
 
 
+def test_filter_with_subnormal_and_huge_rows():
+    """User rows whose largest entry is an fp32 subnormal (the scale 2^-e is not representable) or
+    close to the fp32 maximum, next to ordinary ones."""
+    g = torch.Generator().manual_seed(3)
+    U, I, D, K = 200, 1500, 64, 10
+    ue = torch.randn(U, D, generator=g)
+    ue[0::4] *= 1e-41
+    ue[1::4] *= 1e-37
+    ue[2::4] *= 3e37
+    ie = torch.randn(I, D, generator=g) * 0.5
+    ie[::9] *= 1e-30
+    rng = np.random.default_rng(3)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 2000), rng.integers(0, I, 2000), U)
+    fs, fi = ops.score_topk(ue.to(DEV), ie.to(DEV), K, dev(ptr), dev(mcols), mode="filter")
+    es, ei = ops.score_topk(ue.to(DEV), ie.to(DEV), K, dev(ptr), dev(mcols), mode="exact")
+    assert torch.equal(fi, ei)
+    assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+    assert int((ei >= 0).sum()) == U * K
+
+
 def test_item_offset_and_merge_equal_unsharded():
     """Two item shards ranked separately and merged give the unsharded ranking."""
     rng = np.random.default_rng(4)
