@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void refine_kernel(
     // (normal range) or 2^-25 (below 2^-14, after scaling): |du.i| + |u.di| + |du.di| <=
     // (2^-10 + 2^-22) |u| |i| + 2D 2^-25 2^(eu+ei); the fp32 accumulations of the filter and of the
     // exact chain add at most 2D 2^-24 |u| |i| = 2^-16 (D = 128).  1.25 * 2^-10 and D * 2^-22 bound
-    // the two groups with a margin.  Non-finite embeddings make a norm, hence eps, infinite or NaN:
+    // the two groups with a margin (the matrix unit honours fp16 subnormal inputs: checked with
+    // tools/mfma_denorm_probe.hip).  Non-finite embeddings make a norm, hence eps, infinite or NaN:
     // nothing is certified then and the exact kernel ranks everyone.
     const float eps = 1.25f * 0x1p-10f * unorm[user] * istats[0] + (float)D * 0x1p-22f * back + 1e-30f;
     // Every candidate slot must be filled (kc is at most n_items here): a filter score that is
