@@ -212,7 +212,10 @@ __global__ __launch_bounds__(256) void refine_kernel(
     const float eps = 1.25f * 0x1p-10f * unorm[user] * istats[0] + (float)D * 0x1p-22f * back + 1e-30f;
     // Every candidate slot must be filled (kc is at most n_items here): a filter score that is
     // NaN never ranks, and a user with such scores has to be ranked by the exact kernel.
-    const bool ok = n_valid == kc && (kc >= n_items || a_min + eps < tau);
+    // The K-th score must also lie above the mask score: the filter ranks masked items below
+    // every real score of its (rescaled) units, the exact kernel ranks them at -1e10, above real
+    // scores that are lower still.
+    const bool ok = n_valid == kc && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
       const int32_t pos = atomicAdd(open_count, 1);

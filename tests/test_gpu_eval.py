@@ -199,6 +199,22 @@ def test_filter_with_subnormal_and_huge_rows():
     assert int((ei >= 0).sum()) == U * K
 
 
+def test_filter_when_real_scores_fall_below_the_mask_score():
+    """Scores around -6e11: the masked items (-1e10) are the best ones of the exact ranking, while
+    the filter's own order puts them last.  Nobody may be certified on the filter's word."""
+    g = torch.Generator().manual_seed(5)
+    U, I, D, K = 150, 800, 64, 10
+    ue = torch.randn(U, D, generator=g).abs() * 1e5
+    ie = -torch.randn(I, D, generator=g).abs() * 1e5
+    rng = np.random.default_rng(5)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 1500), rng.integers(0, I, 1500), U)
+    fs, fi = ops.score_topk(ue.to(DEV), ie.to(DEV), K, dev(ptr), dev(mcols), mode="filter")
+    es, ei = ops.score_topk(ue.to(DEV), ie.to(DEV), K, dev(ptr), dev(mcols), mode="exact")
+    assert float(es.max()) == -1e10 and float(es.min()) < -1e10       # masked items lead
+    assert torch.equal(fi, ei)
+    assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+
+
 def test_item_offset_and_merge_equal_unsharded():
     """Two item shards ranked separately and merged give the unsharded ranking."""
     rng = np.random.default_rng(4)
