@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void refine_kernel(
   const int e_sum = (user_ok ? uexp[user] : 0) + scale_exponent(istats[1]);
   const float back = ldexpf(1.0f, e_sum);           // inf / 0 at absurd magnitudes: nothing certified
   const int n_valid = __popc((uint32_t)(__ballot(valid) >> (32 * sub)));
+  // (an exact score that is NaN has no place in the order above: the exact kernel, in which it
+  // never ranks, settles such a user)
+  const bool has_nan = (uint32_t)(__ballot(valid && s != s) >> (32 * sub)) != 0;
   float a_min = valid ? (masked ? kMasked : approx * back) : INFINITY;
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) a_min = fminf(a_min, __shfl_xor(a_min, off, 32));
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void refine_kernel(
     // The K-th score must also lie above the mask score: the filter ranks masked items below
     // every real score of its (rescaled) units, the exact kernel ranks them at -1e10, above real
     // scores that are lower still.
-    const bool ok = n_valid == kc && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
+    const bool ok = n_valid == kc && !has_nan && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
       const int32_t pos = atomicAdd(open_count, 1);

@@ -215,6 +215,22 @@ def test_filter_when_real_scores_fall_below_the_mask_score():
     assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
 
 
+def test_filter_with_fewer_items_than_candidates_and_nan_scores():
+    """Every item is a candidate (I < K + 8) and some exact scores are NaN or infinite."""
+    g = torch.Generator().manual_seed(8)
+    U, I, D, K = 130, 20, 64, 12
+    ue = torch.randn(U, D, generator=g)
+    ie = torch.randn(I, D, generator=g)
+    ie[3, 5] = float("nan")
+    ie[7, 0] = float("inf")
+    ue[11, 2] = float("-inf")
+    for mode_items in (ie, torch.nan_to_num(ie, nan=0.0, posinf=1.0)):
+        fs, fi = ops.score_topk(ue.to(DEV), mode_items.to(DEV), K, mode="filter")
+        es, ei = ops.score_topk(ue.to(DEV), mode_items.to(DEV), K, mode="exact")
+        assert torch.equal(fi, ei)
+        assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+
+
 def test_item_offset_and_merge_equal_unsharded():
     """Two item shards ranked separately and merged give the unsharded ranking."""
     rng = np.random.default_rng(4)
