@@ -133,9 +133,13 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
     const float *__restrict__ W2, const float *__restrict__ b1, const float *__restrict__ b2,
     const float *__restrict__ alpha, float p_drop, uint64_t seed, const uint64_t *__restrict__ seed_step,
     const float *__restrict__ R, int64_t n_rows, float *__restrict__ Y) {
-  // separate arrays: a DMA into one is known not to alias reads of the other
-  __shared__ __attribute__((aligned(1024))) float xa[4][WT * DD];
-  __shared__ __attribute__((aligned(1024))) float xb[DUAL ? 4 : 1][DUAL ? WT * DD : 4];
+  // Two tiles per wavefront and operand, so that TWO tiles are in flight while one is multiplied:
+  // with one (8 KB per wavefront, 32 KB per CU) the kernel waited for memory a third of the time.
+  // Separate arrays: a DMA into one is known not to alias reads of the other.
+  __shared__ __attribute__((aligned(1024))) float xa0[4][WT * DD];
+  __shared__ __attribute__((aligned(1024))) float xa1[4][WT * DD];
+  __shared__ __attribute__((aligned(1024))) float xb0[DUAL ? 4 : 1][DUAL ? WT * DD : 4];
+  __shared__ __attribute__((aligned(1024))) float xb1[DUAL ? 4 : 1][DUAL ? WT * DD : 4];
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
   const int64_t n_tiles = (n_rows + WT - 1) / WT;
@@ -149,8 +153,12 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
 
   uint32_t lane_off = dma_lane_off(lane);
   uint32_t frag_off = frag_lane_off(col, half);
-  stage_rows(X1, tile * WT, n_rows, xa[wave], lane_off);
-  if constexpr (DUAL) stage_rows(X2, tile * WT, n_rows, xb[DUAL ? wave : 0], lane_off);
+  stage_rows(X1, tile * WT, n_rows, xa0[wave], lane_off);
+  if constexpr (DUAL) stage_rows(X2, tile * WT, n_rows, xb0[DUAL ? wave : 0], lane_off);
+  if (tile + stride < n_tiles) {
+    stage_rows(X1, (tile + stride) * WT, n_rows, xa1[wave], lane_off);
+    if constexpr (DUAL) stage_rows(X2, (tile + stride) * WT, n_rows, xb1[DUAL ? wave : 0], lane_off);
+  }
 
   // B operand: W[n = 32t + col][k = 32*half + m], kept in registers for the whole launch
   float w1[2][32], w2[DUAL ? 2 : 1][DUAL ? 32 : 1];
@@ -173,9 +181,10 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
 #pragma unroll
   for (int t = 0; t < 2; ++t) col_term[t] = (uint32_t)((32 * t + col) >> 1) * 0x85EBCA77u ^ seed_lo;
 
-  for (; tile < n_tiles; tile += stride) {
+  // one tile out of buffers (xa, xb), which then receive the tile after next
+  auto process = [&](float *xa, float *xb) {
     const int64_t row0 = tile * WT;
-    const int64_t next = tile + stride;
+    const int64_t next = tile + 2 * stride;
     asm volatile("" : "+v"(lane_off), "+v"(frag_off));   // keep per-piece addresses out of registers
 
     floatx16 acc[2];
@@ -197,21 +206,24 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
         }
     }
 
+    // This tile's DMA (8 pieces per operand, issued a whole tile earlier) must have landed.  Newer
+    // in the in-order memory counter are the 8 stores of the tile in between -- always a full
+    // tile -- and, unless the input has ended, the DMAs of the tile after next: "all but the
+    // newest 8 done" covers both cases and leaves the prefetch in flight.
+    __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8)
     float a[32];
-    load_row_frag(xa[wave], frag_off, a);
-    // the fragment is in registers: the tile buffer is free for the next tile's DMA, which then
-    // has this tile's MFMAs and epilogue to land
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-    if (next < n_tiles) stage_rows(X1, next * WT, n_rows, xa[wave], lane_off);
+    load_row_frag(xa, frag_off, a);
+    // The fragment is in registers.  The buffer first turns the output tile (below) and then takes
+    // the DMA of the tile after next, which has two tiles' MFMAs and epilogues to land.
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int m = 0; m < 32; ++m)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w1[t][m], acc[t], 0, 0, 0);
     if constexpr (DUAL) {
-      load_row_frag(xb[DUAL ? wave : 0], frag_off, a);
+      load_row_frag(xb, frag_off, a);
       __builtin_amdgcn_s_waitcnt(0xC07F);
-      if (next < n_tiles) stage_rows(X2, next * WT, n_rows, xb[DUAL ? wave : 0], lane_off);
+      if (next < n_tiles) stage_rows(X2, next * WT, n_rows, xb, lane_off);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -219,15 +231,18 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w2[DUAL ? t : 0][DUAL ? m : 0], acc[t], 0, 0, 0);
     }
 
-    // epilogue in accumulator layout: lane = column 32t + col, registers = rows.  Compiled four
+    // Epilogue in accumulator layout: lane = column 32t + col, registers = rows.  Compiled four
     // times (dropout on/off, full/partial tile) and selected by two wave-uniform branches per
     // tile, so that the per-element code is straight-line; no activation is alpha = 1.
+    // The results go through the consumed X tile in LDS (plain row-major) and leave as 8 row-wise
+    // 16-byte stores per lane instead of 64 dword stores: the memory counter is shared by loads,
+    // DMAs and stores and holds 63 operations, so with 64 stores per tile every wait for a tile
+    // was a wait for all stores before it as well.
     auto epilogue = [&](auto drop_tag, auto full_tag) {
       constexpr bool kDrop = decltype(drop_tag)::value, kFull = decltype(full_tag)::value;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int n = 32 * t + col;
-        float *yp = Y + row0 * DD + n;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           // rows crow(r) (even) and crow(r) + 1 share one dropout hash
@@ -240,9 +255,16 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
             z = z > 0.0f ? z : al * z;
             if constexpr (kDrop) z = kept(e ? dq.hi : dq.lo, n & 1, thresh) ? z * scale : 0.0f;
             if constexpr (HAS_R) z += res[HAS_R ? t : 0][HAS_R ? r + e : 0];
-            if (kFull || row0 + crow(r + e, half) < n_rows) yp[crow(r + e, half) * DD] = z;
+            xa[crow(r + e, half) * DD + n] = z;
           }
         }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the tile is in LDS
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int row = 4 * p + (lane >> 4);
+        const float4 v = *reinterpret_cast<const float4 *>(xa + row * DD + 4 * (lane & 15));
+        if (kFull || row0 + row < n_rows) *reinterpret_cast<float4 *>(Y + (row0 + row) * DD + 4 * (lane & 15)) = v;
       }
     };
     if (drop) {
@@ -252,6 +274,16 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
       if (full) epilogue(std::false_type{}, std::true_type{});
       else epilogue(std::false_type{}, std::false_type{});
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the output tile has been read back
+    if (next < n_tiles) stage_rows(X1, next * WT, n_rows, xa, lane_off);
+  };
+  for (;;) {
+    process(xa0[wave], xb0[DUAL ? wave : 0]);
+    tile += stride;
+    if (tile >= n_tiles) break;
+    process(xa1[wave], xb1[DUAL ? wave : 0]);
+    tile += stride;
+    if (tile >= n_tiles) break;
   }
 }
 
@@ -545,8 +577,8 @@ inline int cu_count() {
 
 // Persistent grids: one workgroup per CU.  More resident wavefronts measured slower (fewer tiles
 // per wavefront to spread the weight-fragment prologue over, coarser tile quantisation).
-inline int fwd_grid(int64_t n_rows) {
-  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), (int64_t)cu_count());
+inline int fwd_grid(int64_t n_rows, int wg_per_cu) {
+  return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), (int64_t)cu_count() * wg_per_cu);
 }
 constexpr int kBwdMaxGrid = 512;
 inline int bwd_grid(int64_t n_rows) {
@@ -573,7 +605,7 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                    rk::aligned16(Y),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)fwd_grid(n_rows);
+  const unsigned grid = (unsigned)fwd_grid(n_rows, 1);   // a second workgroup per CU measured no faster
   if (X2) {
     if (residual)
       dense_fwd_kernel<true, true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, seed, seed_step, residual, n_rows, Y);
