@@ -1,28 +1,28 @@
 // Fused node-wise layer  Y = dropout(prelu(X1 W1^T [+ X2 W2^T] + b1 [+ b2])) [+ R]
 // and its backward, for the 64-wide embeddings of the propagation hops
-// (gfx950, v_mfma_f32_32x32x2_f32, exact fp32).
+// (gfx950; fp32 results from v_mfma_f32_32x32x16_bf16 on three-way bf16 splits).
 //
 // These are the D x D layers wrapped around every SpMM hop and inside Combine
 // (reference: graph_constructor.py:204, Combin_Layer.py:26-30, out_Layer.py:36,
 // Main_Model.py:162-163).  N is the node count, so each layer is a skinny GEMM
-// that streams an N x 64 matrix once: HBM-bound.  Forward reads X (and R), writes
-// Y.  Backward reads X and G once, RECOMPUTES Z = X W^T + b on the matrix cores
+// that streams an N x 64 matrix once.  Forward reads X (and R), writes Y.
+// Backward reads X and G once, RECOMPUTES Z = X W^T + b on the matrix cores
 // instead of saving it, regenerates the dropout mask from the same counter hash,
 // and produces dX, dW, db and d(alpha) in the same pass; per-workgroup partial
 // sums of dW/db/d(alpha) are reduced in workgroup order by a second launch (no
 // float atomics, bitwise reproducible).
 //
 // Both kernels are persistent and every wavefront works alone on tiles of 32 rows
-// (no workgroup barrier in the loop): it stages its rows by LDS-DMA into a private,
-// XOR-swizzled LDS tile while the previous tile is still being multiplied, keeps
-// the weight fragments in registers for the whole launch, and reads / writes
-// everything else straight from the accumulator layout, whose 32 lanes per row
-// segment make 128-byte coalesced accesses.
+// (no workgroup barrier in the loop): it stages its rows (X, and G in the backward)
+// by LDS-DMA into private, XOR-swizzled LDS tiles one or two tiles ahead, keeps the
+// weight fragments in registers (or LDS) for the whole launch, and sends results
+// through the consumed tile in LDS so that they leave as row-wise 16-byte stores.
 //
-// MFMA operand maps (32x32x2): lane l supplies A[i = l&31][k = l>>5] and
-// B[k = l>>5][j = l&31]; the result register r of lane l is C[(r&3) + 8*(r>>2) +
-// 4*(l>>5)][l&31].  K is walked as (k, k+32) pairs so that a lane's 32 operand
-// values are contiguous in its row.
+// MFMA operand maps (32x32x16): lane l supplies A[i = l&31][k = 8*(l>>5) + j] and
+// B[k = 8*(l>>5) + j][j' = l&31] for j < 8; the result register r of lane l is
+// C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  The reduction index is walked so that a
+// lane's operand values are contiguous in its row: A and B only have to agree on
+// which index a lane's j-th value of a step stands for.
 #include <type_traits>
 
 #include "common.h"
@@ -32,6 +32,49 @@ namespace {
 
 using rk::kWave;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 products on the bf16 matrix pipe.  x = h + m + l with h, m, l bf16 (8 significant bits
+// each: all 24 of an fp32 mantissa, every subtraction below exact), and
+//   x * w = hh + hm + mh + mm + hl + lh   (+ ml + lm + ll, below 2^-24 |x| |w|, dropped):
+// six v_mfma_f32_32x32x16_bf16 of 32 cycles per 16 k against eight fp32-input MFMAs of 64, and,
+// unlike those, not on the vector ALU's issue port.  Sums are fp32 inside the MFMA as before.
+template <int NV>
+struct SplitN {
+  bf16x8 h[NV / 8], m[NV / 8], l[NV / 8];   // element 8s + j is the lane's reduction index 8s + j
+};
+using Split3 = SplitN<32>;
+template <int NV>
+__device__ __forceinline__ void split3(const float (&x)[NV], SplitN<NV> &o) {
+#pragma unroll
+  for (int s4 = 0; s4 < NV / 8; ++s4)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = x[8 * s4 + j];
+      const __bf16 h = (__bf16)v;
+      const float r1 = v - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const float r2 = r1 - (float)m;
+      o.h[s4][j] = h;
+      o.m[s4][j] = m;
+      o.l[s4][j] = (__bf16)r2;
+    }
+}
+// acc += A (32 rows x this lane's NV reduction indices) * B^T in six bf16 products per step of 8;
+// the small terms first, the leading one last
+template <int NV>
+__device__ __forceinline__ void mfma_split3(const SplitN<NV> &a, const SplitN<NV> &b, floatx16 &acc) {
+#pragma unroll
+  for (int s4 = 0; s4 < NV / 8; ++s4) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s4], b.h[s4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.l[s4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b.m[s4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b.h[s4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.m[s4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.h[s4], acc, 0, 0, 0);
+  }
+}
 
 constexpr int DD = 64;        // layer width (in = out)
 constexpr int WT = 32;        // rows per wavefront tile
@@ -93,6 +136,37 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ M, int64_t 
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(M + row * DD) + (off & 255)),
         (__attribute__((address_space(3))) void *)(dst + p * 256), 16, 0, 0);
+  }
+}
+
+// The same staging with the DMA instructions written as inline assembly, for the backward kernel.
+// The compiler's wait-count pass tracks LDS-DMA per LDS array; an access to an array that never
+// receives a DMA (the dZ tile, the weight parts) it cannot place, and it then waits for every
+// DMA in flight (vmcnt(0)), which drains the prefetch of the next tile in the middle of this one.
+// Written this way the pass knows nothing of the DMAs, and the kernel's own s_waitcnt in front of
+// the first read of each tile is the synchronisation.  `row0` and `dst` are wave-uniform.
+__device__ __forceinline__ void stage_rows_raw(const float *__restrict__ M, int64_t row0, int64_t n_rows,
+                                               float *dst, uint32_t lane_off) {
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)dst);
+  if (row0 + WT <= n_rows) {
+    const char *base = reinterpret_cast<const char *>(M + row0 * DD);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t off = (lane_off ^ (uint32_t)(((4 * p) & 15) * 16)) + (uint32_t)(p * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   : : "v"(off), "s"(base), "s"(lds0 + (uint32_t)(p * 1024)) : "memory", "m0");
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const uint32_t off = lane_off ^ (uint32_t)(((4 * p) & 15) * 16);
+    int64_t row = row0 + 4 * p + (int64_t)(off >> 8);
+    row = row < n_rows ? row : n_rows - 1;
+    const char *addr = reinterpret_cast<const char *>(M + row * DD) + (off & 255);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 : : "v"(addr), "s"(lds0 + (uint32_t)(p * 1024)) : "memory", "m0");
   }
 }
 
@@ -161,11 +235,18 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
   }
 
   // B operand: W[n = 32t + col][k = 32*half + m], kept in registers for the whole launch
-  float w1[2][32], w2[DUAL ? 2 : 1][DUAL ? 32 : 1];
+  // (the MFMA sums over (half, j) for each step s: A and B only have to agree on which k a lane's
+  // j-th value is, and both hold k = 32*half + 8s + j)
+  Split3 w1[2], w2[DUAL ? 2 : 1];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    load_w_row(W1, 32 * t + col, half, w1[t]);
-    if constexpr (DUAL) load_w_row(W2, 32 * t + col, half, w2[DUAL ? t : 0]);
+    float wrow[32];
+    load_w_row(W1, 32 * t + col, half, wrow);
+    split3(wrow, w1[t]);
+    if constexpr (DUAL) {
+      load_w_row(W2, 32 * t + col, half, wrow);
+      split3(wrow, w2[DUAL ? t : 0]);
+    }
   }
   float bias[2];
 #pragma unroll
@@ -215,20 +296,17 @@ __global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
     load_row_frag(xa, frag_off, a);
     // The fragment is in registers.  The buffer first turns the output tile (below) and then takes
     // the DMA of the tile after next, which has two tiles' MFMAs and epilogues to land.
+    Split3 as;
+    split3(a, as);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int m = 0; m < 32; ++m)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w1[t][m], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t) mfma_split3(as, w1[t], acc[t]);
     if constexpr (DUAL) {
       load_row_frag(xb, frag_off, a);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       if (next < n_tiles) stage_rows(X2, next * WT, n_rows, xb, lane_off);
+      split3(a, as);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int m = 0; m < 32; ++m)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], w2[DUAL ? t : 0][DUAL ? m : 0], acc[t], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) mfma_split3(as, w2[DUAL ? t : 0], acc[t]);
     }
 
     // Epilogue in accumulator layout: lane = column 32t + col, registers = rows.  Compiled four
@@ -298,9 +376,12 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
     const float *__restrict__ G, int64_t n_rows, float *__restrict__ dX, float *__restrict__ part) {
   __shared__ __attribute__((aligned(1024))) float x0[4][WT * DD];   // X tiles, double buffered:
   __shared__ __attribute__((aligned(1024))) float x1[4][WT * DD];   // the tile is read again for dW
+  __shared__ __attribute__((aligned(1024))) float gt[4][WT * DD];   // G tile, loaded one tile ahead
   __shared__ __attribute__((aligned(16))) float zt[4][WT * LDZ];    // dZ tile (layout change for dX)
   __shared__ float red_b[4][DD + 1];
-  const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+  __shared__ bf16x8 wz_lds[ACT ? 2 : 1][ACT ? 12 : 1][ACT ? kWave : 1];
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);   // in scalar registers: tile addresses are uniform
   const int col = lane & 31, half = lane >> 5;
   const int64_t n_tiles = (n_rows + WT - 1) / WT;
   // the per-call seed, advanced by a step counter in device memory when one is given (a launch
@@ -314,17 +395,38 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
   uint32_t frag_off = frag_lane_off(col, half);
   // column-per-lane read of a staged tile: X[crow(r, half)][32*kt + col]
   uint32_t xcol_off = (uint32_t)(half * 4 * 256 + (((col >> 2) ^ (4 * half)) * 16) + (col & 3) * 4);
-  if (tile < n_tiles) stage_rows(X, tile * WT, n_rows, x0[wave], lane_off);
+  if (tile < n_tiles) {
+    stage_rows_raw(X, tile * WT, n_rows, x0[wave], lane_off);
+    stage_rows_raw(G, tile * WT, n_rows, gt[wave], lane_off);
+  }
 
   // W[n = 32t + col][k = 32*half + m]: B operand of Z = X W^T
-  float wz[ACT ? 2 : 1][ACT ? 32 : 1];
+  // Its bf16 parts are the same for all four wavefronts and are needed once per tile: they wait
+  // in LDS (vector v of lane l at [v][l]: conflict-free 16-byte reads), the registers go to the
+  // operands below.
+  if constexpr (ACT) {
+    if (wave < 2) {
+      float wrow[32];
+      load_w_row(W, 32 * wave + col, half, wrow);
+      Split3 ws;
+      split3(wrow, ws);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        wz_lds[wave][v][lane] = ws.h[v];
+        wz_lds[wave][4 + v][lane] = ws.m[v];
+        wz_lds[wave][8 + v][lane] = ws.l[v];
+      }
+    }
+    __syncthreads();
+  }
   // W[n = 32*half + m][k = 32*kt + col]: B operand of dX = dZ W
-  float wx[2][32];
+  Split3 wx[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    if constexpr (ACT) load_w_row(W, 32 * t + col, half, wz[ACT ? t : 0]);
+    float wrow[32];
 #pragma unroll
-    for (int m = 0; m < 32; ++m) wx[t][m] = dX ? W[(32 * half + m) * DD + 32 * t + col] : 0.0f;
+    for (int m = 0; m < 32; ++m) wrow[m] = dX ? W[(32 * half + m) * DD + 32 * t + col] : 0.0f;
+    split3(wrow, wx[t]);
   }
   const float al = ACT ? alpha[0] : 1.0f;
   const bool drop = p_drop > 0.0f;
@@ -348,28 +450,44 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
       for (int r = 0; r < 16; ++r) dw[t][kt][r] = 0.0f;
   float db_acc[2] = {0.0f, 0.0f}, da_acc = 0.0f;
 
-  // one tile: X in `cur`; the next tile's DMA goes to `nxt`
-  auto do_tile = [&](int64_t tl, const float *cur, float *nxt) {
+  // One tile: X in `cur`; the next tile's DMA goes to `nxt`.  All traffic of a tile is 8 + 8 DMA
+  // instructions (X, G) and 8 row-wise 16-byte stores (dX): the memory counter is in order and
+  // shared by all three, so "G of this tile has landed" is "all but the newest 16 are done" --
+  // the stores of the tile before and the X tile just requested stay in flight.
+  auto do_tile = [&](int64_t tl, float *cur, float *nxt, bool first) {
     const int64_t row0 = tl * WT;
     asm volatile("" : "+v"(lane_off), "+v"(frag_off), "+v"(xcol_off));
-    if (tl + stride < n_tiles) stage_rows(X, (tl + stride) * WT, n_rows, nxt, lane_off);
+    const bool has_next = tl + stride < n_tiles;
+    if (has_next) stage_rows_raw(X, (tl + stride) * WT, n_rows, nxt, lane_off);
+    if (!has_next)
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    else if (first || !dX)
+      __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8): no stores yet / at all
+    else
+      __builtin_amdgcn_s_waitcnt(0x4F70);        // vmcnt(16)
+    asm volatile("" ::: "memory");
 
-    // upstream gradient in accumulator layout (lane = column, registers = rows)
+    // upstream gradient in accumulator layout (lane = column, registers = rows), read
+    // column-per-lane from the staged tile: G[crow(r, half)][32t + col]
     const bool full = row0 + WT <= n_rows;   // wave-uniform: only the last tile can be partial
     float dz[2][16];
-    if (full) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t off = (xcol_off ^ (uint32_t)((r & 3) * 16)) +
+                             (uint32_t)(((r & 3) + 8 * (r >> 2)) * 256 + 8 * (t ^ ((r >> 2) & 1)) * 16);
+        dz[t][r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(gt[wave]) + off);
+      }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): G is in registers, its tile can be refilled
+    asm volatile("" ::: "memory");
+    if (has_next) stage_rows_raw(G, (tl + stride) * WT, n_rows, gt[wave], lane_off);
+    if (!full) {
+      // the staging of a partial tile repeats the last row; those rows have no gradient
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dz[t][r] = G[(row0 + crow(r, half)) * DD + 32 * t + col];
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + crow(r, half);
-          dz[t][r] = row < n_rows ? G[row * DD + 32 * t + col] : 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) dz[t][r] = row0 + crow(r, half) < n_rows ? dz[t][r] : 0.0f;
     }
 
     // A tile whose upstream gradient is all zero contributes nothing to dW, db, d(alpha) and has
@@ -383,13 +501,11 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
         for (int r = 0; r < 16; ++r) bits |= __float_as_uint(dz[t][r]);
       if (!__any((bits << 1) != 0u)) {
         if (dX) {
+          float *dxp = dX + (row0 + (lane >> 4)) * DD + 4 * (lane & 15);
 #pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            float *dxp = dX + row0 * DD + 32 * kt + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (full || row0 + crow(r, half) < n_rows) dxp[crow(r, half) * DD] = 0.0f;
-          }
+          for (int p = 0; p < 8; ++p)
+            if (full || row0 + 4 * p + (lane >> 4) < n_rows)
+              *reinterpret_cast<float4 *>(dxp + 4 * p * DD) = float4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         return;
       }
@@ -403,11 +519,19 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
         for (int r = 0; r < 16; ++r) z[t][r] = 0.0f;
       float a[32];
       load_row_frag(cur, frag_off, a);
+      Split3 as;
+      split3(a, as);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
+        Split3 wz;
 #pragma unroll
-        for (int m = 0; m < 32; ++m)
-          z[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], wz[ACT ? t : 0][ACT ? m : 0], z[t], 0, 0, 0);
+        for (int v = 0; v < 4; ++v) {
+          wz.h[v] = wz_lds[ACT ? t : 0][ACT ? v : 0][ACT ? lane : 0];
+          wz.m[v] = wz_lds[ACT ? t : 0][ACT ? 4 + v : 0][ACT ? lane : 0];
+          wz.l[v] = wz_lds[ACT ? t : 0][ACT ? 8 + v : 0][ACT ? lane : 0];
+        }
+        mfma_split3(as, wz, z[t]);
+      }
     }
     // dZ = dropout mask * scale * G, through the PReLU derivative at the recomputed Z (compiled
     // with and without the mask, selected by one wave-uniform branch per tile)
@@ -443,6 +567,9 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
 
     // dW[n][k] += sum_row dZ[row][n] X[row][k]: A = dZ as it stands (i = n on the lanes, the
     // reduction index walks the rows crow(r, half)), B = X read column-per-lane from the tile
+    SplitN<16> dzs[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) split3(dz[t], dzs[t]);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       float xc[16];
@@ -452,11 +579,10 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
                              (uint32_t)(((r & 3) + 8 * (r >> 2)) * 256 + 8 * (kt ^ ((r >> 2) & 1)) * 16);
         xc[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(cur) + off);
       }
+      SplitN<16> xs;
+      split3(xc, xs);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          dw[t][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[t][r], xc[r], dw[t][kt], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) mfma_split3(dzs[t], xs, dw[t][kt]);
     }
 
     if (dX) {
@@ -470,29 +596,44 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
         a[4 * q + 2] = v.z;
         a[4 * q + 3] = v.w;
       }
+      Split3 as;
+      split3(a, as);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         floatx16 dx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
+        mfma_split3(as, wx[kt], dx);
+        // the X tile has been consumed: it turns the output tile around (plain row-major)
 #pragma unroll
-        for (int m = 0; m < 32; ++m) dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], wx[kt][m], dx, 0, 0, 0);
-        float *dxp = dX + row0 * DD + 32 * kt + col;
-        if (full) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dxp[crow(r, half) * DD] = dx[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (row0 + crow(r, half) < n_rows) dxp[crow(r, half) * DD] = dx[r];
-        }
+        for (int r = 0; r < 16; ++r) cur[crow(r, half) * DD + 32 * kt + col] = dx[r];
       }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      asm volatile("" ::: "memory");
+      const float *src = cur + (lane >> 4) * DD + 4 * (lane & 15);
+      float *dxp = dX + (row0 + (lane >> 4)) * DD + 4 * (lane & 15);
+      if (full) {
+        floatx4 v[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const floatx4 *>(src + 4 * p * DD);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<floatx4 *>(dxp + 4 * p * DD) = v[p];
+      } else {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          if (row0 + 4 * p + (lane >> 4) < n_rows)
+            *reinterpret_cast<float4 *>(dxp + 4 * p * DD) = *reinterpret_cast<const float4 *>(src + 4 * p * DD);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // the tile has been read back before its next DMA
+      asm volatile("" ::: "memory");
     }
   };
 
+  bool first = true;
   for (; tile < n_tiles; tile += 2 * stride) {
-    do_tile(tile, x0[wave], x1[wave]);
-    if (tile + stride < n_tiles) do_tile(tile + stride, x1[wave], x0[wave]);
+    do_tile(tile, x0[wave], x1[wave], first);
+    first = false;
+    if (tile + stride < n_tiles) do_tile(tile + stride, x1[wave], x0[wave], false);
   }
 
   // ---- per-workgroup partials: the four wavefronts' sums are added in wavefront order
