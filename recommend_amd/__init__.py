@@ -12,7 +12,9 @@ from .evaluator import Verifier, Tester, RankingEvaluator
 from .loss import bpr_loss, gather_dot_bpr_loss
 from .sampler import NegativeSampler, TrainBatchLoader, build_user_csr
 from .model import TESTModel, ModelFactory
+from .data import InteractionTable, InteractionSplit, mask_index
 
 __all__ = ["GraphConstructor", "DeviceGraph", "Verifier", "Tester", "RankingEvaluator",
            "bpr_loss", "gather_dot_bpr_loss", "NegativeSampler", "TrainBatchLoader",
-           "build_user_csr", "TESTModel", "ModelFactory", "RkError"]
+           "build_user_csr", "TESTModel", "ModelFactory", "RkError", "InteractionTable",
+           "InteractionSplit", "mask_index"]

@@ -233,6 +233,92 @@ def golden_loader():
         shutil.rmtree(tmp)
 
 
+def golden_data_path():
+    """The reference's dataset class on a table with users that only occur in val / test, a
+    mapping file that makes the id space larger than the ids seen, and two feature files: the
+    splits (graph_data_loader.py:209-247), the per-sample extraction loop of main.py:92-100 run
+    on the reference's __getitem__, the positives index (:163-173) and the groupby expressions of
+    main.mask_index (main.py:127-137; main itself imports DGL and cannot be imported here, so
+    those two pandas expressions are evaluated on the reference's own split DataFrames)."""
+    from data.graph_data_loader import GraphRecDataset
+    U, I = 50, 30
+    rng = np.random.default_rng(17)
+    pairs = np.unique(np.stack([rng.integers(0, U - 4, 700), rng.integers(0, I - 2, 700)], 1), axis=0)
+    pairs = pairs[rng.permutation(len(pairs))][:360]
+    label = rng.choice(3, len(pairs), p=[.7, .15, .15])
+    # users 40..43 never in train
+    label[np.isin(pairs[:, 0], [40, 41, 42, 43]) & (label == 0)] = 1
+    rating = rng.integers(1, 6, len(pairs)).astype(np.float64)
+    tmp = tempfile.mkdtemp()
+    try:
+        with open(os.path.join(tmp, "tiny.inter"), "w") as f:
+            f.write("userID\titemID\trating\tx_label\n")
+            for (u, i), r, l in zip(pairs, rating, label):
+                f.write(f"{u}\t{i}\t{r}\t{l}\n")
+        with open(os.path.join(tmp, "u_id_mapping.csv"), "w") as f:
+            f.write("asin,userID\n" + "".join(f"a{k},{k}\n" for k in range(U)))
+        with open(os.path.join(tmp, "i_id_mapping.csv"), "w") as f:
+            f.write("asin,itemID\n" + "".join(f"b{k},{k}\n" for k in range(I)))
+        np.save(os.path.join(tmp, "item_image_feat.npy"), rng.standard_normal((I, 6)).astype(np.float32))
+        np.save(os.path.join(tmp, "text_feat_item.npy"), rng.standard_normal((I, 4)).astype(np.float32))
+        out = {"inter_text": np.frombuffer(open(os.path.join(tmp, "tiny.inter"), "rb").read(), np.uint8)}
+        for tag, rating_col, filt in [("rated", "rating", True), ("unrated", None, True), ("nofilter", "rating", False)]:
+            cfg = ref_config.get_config("baby")
+            cfg.data.data_path = tmp
+            cfg.data.num_users, cfg.data.num_items = -1, -1
+            cfg.data.rating_col = rating_col
+            cfg.data.filter_out_new_users = filt
+            import warnings as _w
+            with _w.catch_warnings():
+                _w.simplefilter("ignore")
+                full = GraphRecDataset(cfg)
+                splits = full.split()
+            out[f"{tag}/num_users"] = np.array(full.user_num)
+            out[f"{tag}/num_items"] = np.array(full.item_num)
+            out[f"{tag}/item_feature_names"] = np.array(sorted(full.item_features.keys()))
+            for name, ds in zip(("train", "val", "test"), splits):
+                # main.py:92-100 on the reference's own __getitem__
+                us, its, rs = [], [], []
+                for idx in range(len(ds)):
+                    sample = ds[idx]
+                    us.append(sample["user_id"].item())
+                    its.append(sample["item_id"].item())
+                    rs.append(sample["rating"].item() if "rating" in sample else 1)
+                out[f"{tag}/{name}/users"] = np.array(us, np.int64)
+                out[f"{tag}/{name}/items"] = np.array(its, np.int64)
+                out[f"{tag}/{name}/ratings"] = np.array(rs, np.float32)
+            # positives index of the full table, as sorted CSR
+            ptr = [0]
+            cols = []
+            for u in range(full.user_num):
+                its = sorted(int(v) for v in full.user_item_interaction.get(u, ()))
+                cols.extend(its)
+                ptr.append(len(cols))
+            out[f"{tag}/pos_ptr"] = np.array(ptr, np.int64)
+            out[f"{tag}/pos_items"] = np.array(cols, np.int64)
+            # mask_index(config, val, [train]) and (config, test, [train, val])
+            ucol, icol = cfg.data.user_col, cfg.data.item_col
+            for case, target, need in [("val", splits[1], [splits[0]]), ("test", splits[2], [splits[0], splits[1]])]:
+                tr, tc = [], []
+                for user_id, item_id in target.df.groupby(ucol)[icol].apply(list).to_dict().items():
+                    tc.extend(item_id)
+                    tr.extend([user_id] * len(item_id))
+                row_id, col_id = [], []
+                for ds in need:
+                    for user_id, item_id in ds.df.groupby(ucol)[icol].apply(list).to_dict().items():
+                        col_id.extend(item_id)
+                        row_id.extend([user_id] * len(item_id))
+                out[f"{tag}/mask_{case}/target_rows"] = np.array(tr, np.int64)
+                out[f"{tag}/mask_{case}/target_cols"] = np.array(tc, np.int64)
+                out[f"{tag}/mask_{case}/row_id"] = np.array(row_id, np.int64)
+                out[f"{tag}/mask_{case}/col_id"] = np.array(col_id, np.int64)
+        out["item_image_feat"] = np.load(os.path.join(tmp, "item_image_feat.npy"))
+        out["text_feat_item"] = np.load(os.path.join(tmp, "text_feat_item.npy"))
+        np.savez_compressed(os.path.join(OUT, "data_path.npz"), **out)
+    finally:
+        shutil.rmtree(tmp)
+
+
 def golden_config():
     d = {name: ref_config.get_config(name).to_dict() for name in ["baby", "clothing", "sports", "elec"]}
     with open(os.path.join(OUT, "config_presets.json"), "w") as f:
@@ -245,5 +331,6 @@ if __name__ == "__main__":
     golden_verifier()
     golden_losses()
     golden_loader()
+    golden_data_path()
     golden_config()
     print("golden fixtures written to", OUT)

@@ -371,3 +371,33 @@ def test_rows_topk_ties_and_oracle():
         order = np.lexsort((np.broadcast_to(np.arange(I), (B, I)), -s), axis=1)[:, :K]
         assert np.array_equal(ids.cpu().numpy(), order.astype(np.int32))
         assert np.array_equal(vals.cpu().numpy(), np.take_along_axis(s, order, 1))
+
+
+def test_sparse_pairs_from_the_data_path_equal_the_dense_target():
+    """The (row, col) pairs of recommend_amd.data.mask_index give the same metrics as the dense
+    [U, I] target matrix and python-list mask of main.mask_index built from the same splits."""
+    from recommend_amd import data as rdata
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_path.npz"))
+    U, I = int(z["rated/num_users"]), int(z["rated/num_items"])
+    splits = [rdata.InteractionSplit(z[f"rated/{n}/users"], z[f"rated/{n}/items"], z[f"rated/{n}/ratings"], n)
+              for n in ("train", "val", "test")]
+    target_pairs, mask = rdata.mask_index(splits[2], splits[:2])
+    dense = torch.zeros(U, I)
+    dense[torch.from_numpy(target_pairs[0]), torch.from_numpy(target_pairs[1])] = 1
+    g = torch.Generator().manual_seed(3)
+    ue = torch.randn(U, 64, generator=g).to(DEV)
+    ie = torch.randn(I, 64, generator=g).to(DEV)
+    ks, names = [5, 10, 20], ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
+    a = RankingEvaluator(target_pairs, mask, ks, names, n_users=U).evaluate(ue, ie)
+    b = RankingEvaluator(dense, (mask[0].tolist(), mask[1].tolist()), ks, names).evaluate(ue, ie)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+    # and against the CPU oracle on the same embeddings
+    ptr, cols = pairs_to_csr(mask[0], mask[1], U)
+    _s, ids = eval_oracle.score_topk(ue.cpu().numpy(), ie.cpu().numpy(), 20, ptr, cols)
+    tp, tc = pairs_to_csr(target_pairs[0], target_pairs[1], U)
+    want = eval_oracle.metrics_from_topk_sparse(ids, tp, tc, ks)
+    for k in ks:
+        assert abs(float(a[f"recall@{k}"]) - want[k]["recall"]) <= 1e-6
+        assert abs(float(a[f"ndcg@{k}"]) - want[k]["ndcg"]) <= 1e-6
