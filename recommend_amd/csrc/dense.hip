@@ -716,8 +716,7 @@ inline int cu_count() {
   return cached;
 }
 
-// Persistent grids: one workgroup per CU.  More resident wavefronts measured slower (fewer tiles
-// per wavefront to spread the weight-fragment prologue over, coarser tile quantisation).
+// Persistent grids: as many workgroups per CU as the variant's registers and LDS let be resident.
 inline int fwd_grid(int64_t n_rows, int wg_per_cu) {
   return (int)std::min<int64_t>(rk::ceil_div(rk::ceil_div(n_rows, WT), 4), (int64_t)cu_count() * wg_per_cu);
 }
@@ -746,7 +745,10 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                    rk::aligned16(Y),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)fwd_grid(n_rows, 1);   // a second workgroup per CU measured no faster
+  // the plain layer fits two workgroups per CU (256 registers, 64 KB of LDS): a second wavefront per
+  // SIMD splits operands and runs the epilogue while the first one multiplies (32.6 -> 29.9 us at
+  // 255k rows); the two-input and the residual variants need the whole CU
+  const unsigned grid = (unsigned)fwd_grid(n_rows, (X2 || residual) ? 1 : 2);
   if (X2) {
     if (residual)
       dense_fwd_kernel<true, true><<<grid, 256, 0, st>>>(X1, W1, X2, W2, b1, b2, alpha, p_drop, seed, seed_step, residual, n_rows, Y);
