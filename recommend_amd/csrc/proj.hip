@@ -1,11 +1,14 @@
-// Modality projection Y = [b ; X W^T + b] and its weight/bias gradients on the
-// fp32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+// Modality projection Y = [b ; X W^T + b] and its weight/bias gradients on the matrix cores,
+// gfx950: the forward multiplies three-way bf16 splits of the fp32 operands
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32-level error), the weight gradient uses the
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32).
 //
 // The reference pads the item feature matrix with one all-zero row per user
 // and runs nn.Linear over all U+I rows; a zero row times W is exactly zero, so
 // the user rows of the output are the bias and only the I item rows need a
 // GEMM.  Forward: 128 x 64 output tile per workgroup (4 wavefronts x 32 rows),
-// K streamed 32 columns at a time through double-buffered, padded LDS tiles.
+// K streamed 32 columns at a time, two tiles in flight in registers, split into
+// bf16 parts on the way into double-buffered, XOR-swizzled LDS tiles.
 // Backward: dW = dY_items^T X is a GEMM whose reduction runs over the items;
 // it is cut into item slices whose 64 x 128 partial tiles are summed in slice
 // order by a second kernel (deterministic, no float atomics).
@@ -16,9 +19,9 @@ namespace {
 
 using rk::kWave;
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 64, BK = 32;
-constexpr int LDA = BK + 4;  // padded LDS row (floats): conflict-free b128 reads
 
 __global__ __launch_bounds__(256) void proj_fill_users_kernel(const float *__restrict__ b, int32_t D,
                                                               int64_t n, float *__restrict__ Y) {
@@ -26,43 +29,122 @@ __global__ __launch_bounds__(256) void proj_fill_users_kernel(const float *__res
   if (i < n) Y[i] = b ? b[i % D] : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void proj_fwd_kernel(const float *__restrict__ X, int32_t n_items,
-                                                       int32_t F, const float *__restrict__ W,
-                                                       const float *__restrict__ b, int32_t D,
-                                                       float *__restrict__ Yitems) {
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDA];
+// fp32 products on the bf16 matrix pipe: x = h + m + l with h, m, l bf16 (3 x 8 significant bits =
+// the whole fp32 mantissa; the subtractions are exact) and
+//   x * w = hh + hm + mh + mm + hl + lh   (+ ml + lm + ll, below 2^-24 |x| |w|, dropped):
+// six v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16 k against eight fp32-input MFMAs of 64.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct Parts4 {
+  bf16x4 h, m, l;
+};
+__device__ __forceinline__ Parts4 split4(const floatx4 &v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  Parts4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r1 = x[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    o.h[j] = h;
+    o.m[j] = m;
+    o.l[j] = (__bf16)(r1 - (float)m);
+  }
+  return o;
+}
+__device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], floatx16 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// the same for two accumulators that share A, alternating so that no MFMA waits for the one before
+__device__ __forceinline__ void mfma6x2(const bf16x8 (&a)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3],
+                                        floatx16 &acc0, floatx16 &acc1) {
+  constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia[p]], b0[ib[p]], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia[p]], b1[ib[p]], acc1, 0, 0, 0);
+  }
+}
+
+// LDS tile of one operand: three bf16 planes (h, m, l) of ROWS x 32 k, 64 bytes per row, the 16-byte
+// chunk c of row r stored at chunk c ^ ((r >> 2) & 3).  A ds_read_b128 is served in groups of 16
+// lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32) over a 256-byte bank row = 4 tile
+// rows: the four rows of a group that share r mod 4 differ in (r >> 2) & 3, so the MFMA operand
+// reads (row per lane, chunk 2s + half) are conflict free without padding.
+__device__ __forceinline__ uint32_t tile_off(int r, int chunk) {
+  return (uint32_t)(r * 64 + ((chunk ^ ((r >> 2) & 3)) * 16));
+}
+
+__global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float *__restrict__ X, int32_t n_items,
+                                                          int32_t F, const float *__restrict__ W,
+                                                          const float *__restrict__ b, int32_t D,
+                                                          float *__restrict__ Yitems) {
+  constexpr int APL = BM * 64, BPL = BN * 64;   // bytes per plane
+  __shared__ __attribute__((aligned(16))) char As[2][3 * APL];
+  __shared__ __attribute__((aligned(16))) char Bs[2][3 * BPL];
   const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
   const int col = lane & 31, half = lane >> 5;
   const int32_t m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-  float4 sa[4], sb[2];
-  auto load = [&](int32_t k0) {
+  // Two K tiles are on their way from memory at any time (register sets 0 / 1): one step of
+  // MFMAs is shorter than the memory latency, and with a single tile in flight every step ended
+  // waiting for it.  Loads are unconditional (rows past the end re-read the last row: their
+  // results are never stored; columns past F re-read the last chunk and are zeroed on their way
+  // into LDS) and written as inline assembly with the kernel's own s_waitcnt in front of the
+  // first use: across the loop's back edge the compiler's wait-count pass otherwise waits for the
+  // newest loads (vmcnt(0)) before it issues the next tile's, which serialises memory and
+  // arithmetic.  These loads are the only vector-memory operations in the loop.
+  floatx4 sa[2][4], sb[2][2];
+  auto load = [&](int32_t k0, floatx4 (&ra)[4], floatx4 (&rb)[2]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = tid + 256 * j, r = e >> 3, c = (e & 7) * 4;
-      sa[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + r < n_items && k0 + c < F)
-        sa[j] = *reinterpret_cast<const float4 *>(X + (int64_t)(m0 + r) * F + k0 + c);
+      const float *src = X + (int64_t)min(m0 + r, n_items - 1) * F + min(k0 + c, F - 4);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[j]) : "v"(src));
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int e = tid + 256 * j, r = e >> 3, c = (e & 7) * 4;
-      sb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + r < D && k0 + c < F)
-        sb[j] = *reinterpret_cast<const float4 *>(W + (int64_t)(n0 + r) * F + k0 + c);
+      const float *src = W + (int64_t)min(n0 + r, D - 1) * F + min(k0 + c, F - 4);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[j]) : "v"(src));
     }
   };
-  auto store = [&](int buf) {
+  // all loads but the newest `newer` have landed; the registers pass through the statement so that
+  // no use of them can be scheduled ahead of it
+  auto landed = [&](bool newer6, floatx4 (&ra)[4], floatx4 (&rb)[2]) {
+    if (newer6)
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]));
+  };
+  // every value is split once per workgroup, on its way from the registers into LDS
+  const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto store = [&](int buf, int32_t k0, const floatx4 (&ra)[4], const floatx4 (&rb)[2]) {
+    const bool k_in = k0 + (tid & 7) * 4 < F;   // (e & 7) = (tid & 7) for every j
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int e = tid + 256 * j;
-      *reinterpret_cast<float4 *>(&As[buf][(e >> 3) * LDA + (e & 7) * 4]) = sa[j];
+      const int e = tid + 256 * j, r = e >> 3, q = e & 7;   // 4 values = half a 16-byte chunk
+      const Parts4 p = split4(k_in ? ra[j] : zero4);
+      char *dst = &As[buf][tile_off(r, q >> 1) + 8 * (q & 1)];
+      *reinterpret_cast<bf16x4 *>(dst) = p.h;
+      *reinterpret_cast<bf16x4 *>(dst + APL) = p.m;
+      *reinterpret_cast<bf16x4 *>(dst + 2 * APL) = p.l;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int e = tid + 256 * j;
-      *reinterpret_cast<float4 *>(&Bs[buf][(e >> 3) * LDA + (e & 7) * 4]) = sb[j];
+      const int e = tid + 256 * j, r = e >> 3, q = e & 7;
+      const Parts4 p = split4(k_in ? rb[j] : zero4);
+      char *dst = &Bs[buf][tile_off(r, q >> 1) + 8 * (q & 1)];
+      *reinterpret_cast<bf16x4 *>(dst) = p.h;
+      *reinterpret_cast<bf16x4 *>(dst + BPL) = p.m;
+      *reinterpret_cast<bf16x4 *>(dst + 2 * BPL) = p.l;
     }
   };
 
@@ -72,30 +154,42 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const float *__restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // Every workgroup starts its walk over K at another column: rows are F * 4 bytes apart (16 KB at
+  // F = 4096), so workgroups in step would all ask the same few memory channels at any moment.
   const int32_t nk = (F + BK - 1) / BK;
-  load(0);
-  store(0);
-  __syncthreads();
-  for (int32_t kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load((kt + 1) * BK);
+  const int32_t kofs = (int32_t)((blockIdx.x * 37u) % (uint32_t)nk);
+  auto ktile = [&](int32_t kt) { return ((kt + kofs) % nk) * BK; };
+  // tile j waits in register set j & 1 until it is stored into LDS buffer j & 1
+  auto step = [&](int32_t kt, int cur) {   // cur = kt & 1, a constant at each call site
+    if (kt + 2 < nk) load(ktile(kt + 2), sa[cur], sb[cur]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // lane half h takes columns 8j+4h .. 8j+4h+3 of the K tile
-      const float4 a = *reinterpret_cast<const float4 *>(&As[buf][(wave * 32 + col) * LDA + 8 * j + 4 * half]);
-      const float4 b0 = *reinterpret_cast<const float4 *>(&Bs[buf][col * LDA + 8 * j + 4 * half]);
-      const float4 b1 = *reinterpret_cast<const float4 *>(&Bs[buf][(32 + col) * LDA + 8 * j + 4 * half]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // step s2 covers k = 16 s2 .. 16 s2 + 15 of the tile; lane half h supplies chunk 2 s2 + h
+      bf16x8 a[3], b0[3], b1[3];
+      const uint32_t oa = tile_off(wave * 32 + col, 2 * s2 + half);
+      const uint32_t ob0 = tile_off(col, 2 * s2 + half), ob1 = tile_off(32 + col, 2 * s2 + half);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[p] = *reinterpret_cast<const bf16x8 *>(&As[cur][p * APL + oa]);
+        b0[p] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][p * BPL + ob0]);
+        b1[p] = *reinterpret_cast<const bf16x8 *>(&Bs[cur][p * BPL + ob1]);
+      }
+      mfma6x2(a, b0, b1, acc[0], acc[1]);
     }
-    if (kt + 1 < nk) store(buf ^ 1);
+    if (kt + 1 < nk) {
+      landed(kt + 2 < nk, sa[cur ^ 1], sb[cur ^ 1]);
+      store(cur ^ 1, ktile(kt + 1), sa[cur ^ 1], sb[cur ^ 1]);
+    }
     __syncthreads();
+  };
+  load(ktile(0), sa[0], sb[0]);
+  if (nk > 1) load(ktile(1), sa[1], sb[1]);
+  landed(nk > 1, sa[0], sb[0]);
+  store(0, ktile(0), sa[0], sb[0]);
+  __syncthreads();
+  for (int32_t kt = 0; kt < nk; kt += 2) {
+    step(kt, 0);
+    if (kt + 1 < nk) step(kt + 1, 1);
   }
   // C layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half
 #pragma unroll
