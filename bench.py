@@ -323,6 +323,24 @@ def main():
             cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \
                                   "oracle's MMFCN at the same shape, no warm-up step"
 
+    # N > 1: one row-sharded propagation hop (all-gather of the layer over RCCL + local SpMM on the
+    # rank's rows), outside the timed region; the slowest rank counts.
+    sharded_hop = None
+    if world > 1:
+        try:
+            from recommend_amd.dist import RowShardedGraph, all_reduce_tensor
+            wn = gc.graph.edata[gc.weight].detach().cpu().numpy()
+            rg = RowShardedGraph(gc.graph.src, gc.graph.dst, wn, N, rank, world, device=dev)
+            h_loc = torch.randn(rg.hi - rg.lo, D, device=dev)
+            rg.hop(h_loc)
+            dist.barrier()
+            t = torch.tensor([event_ms(lambda: rg.hop(h_loc), 20)], dtype=torch.float64, device=dev)
+            all_reduce_tensor(t, dist.ReduceOp.MAX)
+            sharded_hop = {"ms_per_hop": round(float(t), 5), "rows_per_rank": rg.block,
+                           "all_gather_bytes_total": N * D * 4,
+                           "note": "all-gather of the layer + SpMM on this rank's rows; max over ranks"}
+        except Exception as e:  # reported, never fatal for the headline line
+            sharded_hop = {"error": repr(e)}
     if rank == 0:
         line = {
             "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
@@ -333,12 +351,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
                                    f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
-                       "parallelism": "single GPU" if world == 1 else f"items sharded over {world} GPUs, all-gather + merge"},
+                       "parallelism": "single GPU" if world == 1 else f"items sharded over {world} GPUs, exchange of the per-user top-K lists + merge"},
             "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
             "spmm_transpose_ms": round(ms_spmm_t, 5),
             "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
             "recall@20": round(float(res["recall@20"]), 6),
         }
+        if sharded_hop is not None:
+            line["row_sharded_hop"] = sharded_hop
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

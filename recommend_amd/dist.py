@@ -10,6 +10,9 @@ times as much for lists the receiver never reads.  Each rank reduces the metric
 sums of its slice and one all-reduce of 6*len(k_list) doubles finishes the means.
 Contiguous item ranges keep "lower id wins" valid across shards.
 
+Propagation over graphs too large for one GPU shards the ROWS (RowShardedGraph at the
+end of this file): one all-gather of the layer per hop, forward and backward.
+
 The reference is single-process (no collective anywhere in its tree); this file
 has no counterpart there.  `compute` is the module that provides score_topk /
 topk_merge / rank_metrics: recommend_amd.ops (HIP) in production.
@@ -137,3 +140,101 @@ class ShardedRankingEvaluator:
             for name in self.metrics:
                 out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
         return out
+
+
+# --------------------------------------------------------------------------
+# Row-sharded propagation: rank r owns the destination rows [lo_r, hi_r) of the adjacency and the
+# matching rows of every layer's embeddings.  One hop needs every source row, so it is one
+# all-gather of the layer (N*D*4 bytes in total) followed by the local SpMM; the backward pass is
+# the same step with the transposed operand (rank r owns rows [lo_r, hi_r) of A^T), i.e. one
+# all-gather of the gradient.  Blocks are equal (ceil(N / world), the last one short) so that the
+# gather needs no size exchange.
+# --------------------------------------------------------------------------
+def node_range(n_nodes, rank, world):
+    block = -(-n_nodes // world)
+    lo = min(rank * block, n_nodes)
+    return lo, min(lo + block, n_nodes)
+
+
+def _rows_csr(rows, cols, lo, hi):
+    """CSR of the edges whose row falls in [lo, hi), rows re-based to lo, stable in edge order.
+    Returns (rowptr int32 [hi-lo+1], col int32, edge ids int64 into the full list)."""
+    rows = np.asarray(rows, np.int64)
+    sel = np.nonzero((rows >= lo) & (rows < hi))[0]
+    order = sel[np.argsort(rows[sel], kind="stable")]
+    ptr = np.zeros(hi - lo + 1, np.int64)
+    np.cumsum(np.bincount(rows[order] - lo, minlength=hi - lo), out=ptr[1:])
+    return ptr.astype(np.int32), np.asarray(cols, np.int32)[order], order
+
+
+class HipRowBlock:
+    """The production compute of a row block: recommend_amd.ops SpMM kernels."""
+
+    def __init__(self, rowptr, col, val, device):
+        from . import ops
+        self._ops = ops
+        eid = np.arange(col.shape[0], dtype=np.int32)
+        self.mat = ops.CsrMatrix(rowptr, col, eid, device)
+        self.mat.set_values_from_coo(torch.from_numpy(np.ascontiguousarray(val, np.float32)).to(device))
+
+    def matmul(self, h_full):
+        return self._ops.spmm_raw(self.mat, h_full)
+
+
+class _ShardedHop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h_local, graph):
+        ctx.graph = graph
+        return graph.fwd.matmul(graph.gather_rows(h_local))
+
+    @staticmethod
+    def backward(ctx, g_local):
+        graph = ctx.graph
+        return graph.bwd.matmul(graph.gather_rows(g_local.contiguous())), None
+
+
+class RowShardedGraph:
+    """src/dst/w: the full COO edge list with its (normalised) values, as the reference's
+    GraphConstructor holds it (every rank reads the same list and keeps its rows only).
+    `block_factory(rowptr, col, val, device)` returns an object with `matmul(h_full)`;
+    HipRowBlock in production."""
+
+    def __init__(self, src, dst, w, n_nodes, rank=None, world=None, group=None, device="cuda",
+                 block_factory=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.n_nodes = int(n_nodes)
+        self.block = -(-self.n_nodes // self.world)
+        self.lo, self.hi = node_range(self.n_nodes, self.rank, self.world)
+        factory = block_factory or HipRowBlock
+        w = np.asarray(w, np.float32)
+        p, c, e = _rows_csr(dst, src, self.lo, self.hi)       # out[v] = sum over edges u -> v
+        self.fwd = factory(p, c, w[e], device)
+        p, c, e = _rows_csr(src, dst, self.lo, self.hi)       # rows of the transposed operand
+        self.bwd = factory(p, c, w[e], device)
+
+    def local_rows(self, x_full):
+        return x_full[self.lo:self.hi]
+
+    def gather_rows(self, x_local):
+        """[hi-lo, D] on every rank -> the full [N, D] matrix on every rank."""
+        if self.world == 1:
+            return x_local
+        n_loc, D = x_local.shape
+        if n_loc < self.block:
+            pad = torch.zeros((self.block - n_loc, D), dtype=x_local.dtype, device=x_local.device)
+            x_local = torch.cat([x_local, pad])
+        parts = all_gather_tensor(x_local.contiguous(), self.world, self.group)
+        return torch.cat(parts)[: self.n_nodes]
+
+    def hop(self, h_local):
+        """One hop h <- A h on this rank's rows (differentiable)."""
+        return _ShardedHop.apply(h_local, self)
+
+    def aggrate(self, x_local, k, alpha):
+        """k hops of h <- alpha*h0 + (1-alpha)*A h (graph_constructor.py:189-197), rows sharded."""
+        h = x_local
+        for _ in range(k):
+            h = alpha * x_local + (1.0 - alpha) * self.hop(h)
+        return h

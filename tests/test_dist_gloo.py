@@ -113,3 +113,80 @@ def test_item_sharded_eval_world2_equals_unsharded():
             for m in METRICS:
                 assert abs(res[f"{m}@{k}"] - want[k][m]) <= 1e-6, (rank, m, k)
     assert results[0][1] == results[1][1]                                  # every rank holds the same metrics
+
+
+# ------------------------------------------------------------------ row-sharded propagation
+class OracleRowBlock:
+    """matmul(h_full) of one row block in float64 scipy (test-only stand-in for HipRowBlock)."""
+
+    def __init__(self, rowptr, col, val, device):
+        import scipy.sparse as sp
+        n_cols = int(col.max()) + 1 if col.size else 1
+        self.n_cols = n_cols
+        self.m = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(rowptr.shape[0] - 1, n_cols))
+
+    def matmul(self, h_full):
+        h = h_full.detach().numpy().astype(np.float64)[: self.n_cols]
+        return torch.from_numpy((self.m @ h).astype(np.float32))
+
+
+def _prop_case():
+    rng = np.random.default_rng(3)
+    N, E, D = 101, 700, 16                     # 101 rows over 2 ranks: blocks of 51 and 50
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    src[:5], dst[:5] = N - 1, np.arange(5)     # the last node has edges both ways
+    dst[5:10], src[5:10] = N - 1, np.arange(5)
+    w = rng.random(E).astype(np.float32)       # NOT symmetric: the backward needs the true transpose
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    g = rng.standard_normal((N, D)).astype(np.float32)
+    return N, src, dst, w, x, g
+
+
+def _prop_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from recommend_amd.dist import RowShardedGraph, node_range
+        N, src, dst, w, x, g = _prop_case()
+        graph = RowShardedGraph(src, dst, w, N, device="cpu", block_factory=OracleRowBlock)
+        assert (graph.lo, graph.hi) == node_range(N, rank, world)
+        xl = torch.from_numpy(x[graph.lo:graph.hi]).requires_grad_(True)
+        out = graph.aggrate(xl, 3, 0.2)
+        out.backward(torch.from_numpy(g[graph.lo:graph.hi]))
+        q.put((rank, graph.lo, graph.hi, out.detach().numpy(), xl.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_propagation_world2_equals_unsharded():
+    import scipy.sparse as sp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    N, src, dst, w, x, g = _prop_case()
+    A = sp.csr_matrix((w.astype(np.float64), (dst, src)), shape=(N, N))   # duplicates add up
+    h0 = x.astype(np.float64)
+    h = h0
+    for _ in range(3):
+        h = 0.2 * h0 + 0.8 * (A @ h)
+    # gradient of sum(out * g) wrt x through the same recurrence
+    gh = g.astype(np.float64)
+    gx = np.zeros_like(gh)
+    for _ in range(3):
+        gx += 0.2 * gh
+        gh = 0.8 * (A.T @ gh)
+    gx += gh
+    assert sorted((lo, hi) for _r, lo, hi, _o, _g in results) == [(0, 51), (51, 101)]
+    for _rank, lo, hi, out, grad in results:
+        assert np.abs(out - h[lo:hi]).max() <= 1e-5 * np.abs(h).max()
+        assert np.abs(grad - gx[lo:hi]).max() <= 1e-5 * np.abs(gx).max()
