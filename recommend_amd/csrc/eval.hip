@@ -316,8 +316,9 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
 #undef RK_EXACT_CASE
   if (rc != RK_OK) return rc;
   const int32_t rpu = sel.list != nullptr ? 1 : 0;
-  if (nsplit * kp <= MERGE_MAX) return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, rpu, out_scores, out_ids, st);
-  // too many lists for one merge (the compacted launch): groups of kMergeGroup lists first
+  if (nsplit <= kMergeGroup) return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, rpu, out_scores, out_ids, st);
+  // many lists (the compacted launch): groups of kMergeGroup lists first.  The bisection merge costs
+  // lists x entries per row: 48 lists in one go took 0.7 ms for a few hundred rows.
   const int groups = nsplit / kMergeGroup;   // open_nsplit() makes this exact
   float *gs = (float *)(pi + (size_t)n_users * nsplit * kp);
   int32_t *gi = (int32_t *)(gs + (size_t)n_users * groups * kp);
@@ -337,8 +338,8 @@ inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpen
 inline int open_nsplit(int32_t n_items, int32_t K) {
   const int64_t tiles = rk::ceil_div(n_items, TI);
   const int64_t want = std::max<int64_t>(1, std::min<int64_t>(128, tiles / 4));
-  if (want * kpad_for(K) <= MERGE_MAX) return (int)want;   // one merge
-  return (int)(want / kMergeGroup * kMergeGroup);          // two: whole groups (want >= 32 here)
+  if (want <= kMergeGroup) return (int)want;               // one merge
+  return (int)(want / kMergeGroup * kMergeGroup);          // two: whole groups
 }
 // floats + ints of the compacted launch: its partial lists and the intermediate merge results
 inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
@@ -348,12 +349,17 @@ inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
 
 // candidate list length of the filter pass for a final K (0: no filter pass, K too large)
 // Item slices of the filter launch: as for the exact one, at the filter's occupancy, but at least
-// two where the items allow (measured: a single slice, with every workgroup of the grid walking
-// the table at the same position, runs half as fast per tile), and no more than the exact launch
-// uses (the workspace is sized for that).
+// two on long tables (measured at 1969 tiles: a single slice, with every workgroup of the grid
+// walking the table at the same position, runs half as fast per tile), and no more than the exact
+// launch uses (the workspace is sized for that).  Short tables (an item shard of a multi-GPU
+// evaluation) take ONE slice: every slice starts an empty list per user, and the ~K ln(n/K)
+// insertions of a list's start-up are what such a launch spends its time on; one slice also needs
+// no merge.  Measured at 192k users: 246 tiles 2.36 -> 2.17 ms per call, 492 tiles even.
+constexpr int kShortTableTiles = 512;
 inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
+  if (rk::ceil_div(n_items, TI) <= kShortTableTiles) return 1;
   int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
-  if (ns == 1 && rk::ceil_div(n_items, TI) >= 8) ns = 2;
+  if (ns == 1) ns = 2;
   return std::min(ns, std::max(2, choose_nsplit(n_users, n_items)));
 }
 
@@ -484,10 +490,13 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   float *ps = (float *)(base + w.part);
   int32_t *pi = (int32_t *)(ps + (size_t)n_users * fsplit * kc);
   const int grid = (int)rk::ceil_div(n_users, UPB) * fsplit;
+  // a single slice's lists ARE the candidates (sorted, unfilled places -inf / -1): no merge
+  const bool direct = fsplit == 1 && n_items >= kc;
   if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, uhalf, n_users, ihalf, n_items, mask_ptr, mask_items,
-                                   fsplit, ps, pi)) != RK_OK)
+                                   fsplit, direct ? cand_s : ps, direct ? cand_id : pi)) != RK_OK)
     return rc;
-  if ((rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, 0, cand_s, cand_id, st)) != RK_OK)
+  if (!direct &&
+      (rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, 0, cand_s, cand_id, st)) != RK_OK)
     return rc;
   // 3. exact scores of the candidates, final order, certification
   if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, std::min(kc, n_items), K, unorm,
