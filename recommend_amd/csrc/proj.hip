@@ -23,10 +23,14 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 64, BK = 32;
 
+// user rows of the output: the bias, four columns per thread (D is a multiple of 4, Y 16-byte aligned)
 __global__ __launch_bounds__(256) void proj_fill_users_kernel(const float *__restrict__ b, int32_t D,
-                                                              int64_t n, float *__restrict__ Y) {
+                                                              int64_t n4, float *__restrict__ Y) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) Y[i] = b ? b[i % D] : 0.0f;
+  if (i >= n4) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b) v = *reinterpret_cast<const float4 *>(b + (i * 4) % D);
+  reinterpret_cast<float4 *>(Y)[i] = v;
 }
 
 // fp32 products on the bf16 matrix pipe: x = h + m + l with h, m, l bf16 (3 x 8 significant bits =
@@ -309,11 +313,12 @@ int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, 
   RK_CHECK_ARG(n_items >= 0 && n_users >= 0 && F > 0 && D > 0, "bad sizes");
   RK_CHECK_ARG(F % 4 == 0 && D % 4 == 0, "feature and embedding widths must be multiples of 4");
   RK_CHECK_ARG(W && Y && (n_items == 0 || X), "null pointer");
-  RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(Y), "matrices must be 16-byte aligned");
+  RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(Y) && rk::aligned16(b),
+               "matrices and bias must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nu = (int64_t)n_users * D;
   if (nu > 0) {
-    proj_fill_users_kernel<<<(unsigned)rk::ceil_div(nu, 256), 256, 0, st>>>(b, D, nu, Y);
+    proj_fill_users_kernel<<<(unsigned)rk::ceil_div(nu / 4, 256), 256, 0, st>>>(b, D, nu / 4, Y);
     RK_CHECK_LAUNCH("proj_fill_users_kernel");
   }
   if (n_items > 0) {

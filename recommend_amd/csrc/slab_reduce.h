@@ -81,10 +81,63 @@ constexpr int kColsumRows = 1024;
 
 __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ M, int64_t rows,
                                                      int32_t D, float *__restrict__ part) {
-  __shared__ float red[4][64];
-  const int tid = threadIdx.x, q = tid >> 6;
+  const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
   const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
+  const int32_t G = D / 4;   // 16-byte column groups per row
+  if (D % 4 == 0 && G <= 256 && 256 % G == 0 && ((reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(part)) & 15) == 0) {
+    // G lanes read one row as float4, 256 / G rows per pass, eight passes in flight: the kernel has
+    // one workgroup per 1024 rows and lives on the loads it keeps outstanding
+    __shared__ float4 red4[256];
+    const int32_t g = tid % G, rr = tid / G, RP = 256 / G;
+    float4 acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *src = reinterpret_cast<const float4 *>(M) + g;
+    int64_t r = r0 + rr;
+    for (; r + 7 * RP < r1; r += 8 * RP) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(r + (int64_t)u * RP) * G];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc[u].x += v[u].x;
+        acc[u].y += v[u].y;
+        acc[u].z += v[u].z;
+        acc[u].w += v[u].w;
+      }
+    }
+    for (; r < r1; r += RP) {
+      const float4 v = src[r * G];
+      acc[0].x += v.x;
+      acc[0].y += v.y;
+      acc[0].z += v.z;
+      acc[0].w += v.w;
+    }
+    float4 t = acc[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) {
+      t.x += acc[u].x;
+      t.y += acc[u].y;
+      t.z += acc[u].z;
+      t.w += acc[u].w;
+    }
+    red4[tid] = t;
+    __syncthreads();
+    if (rr == 0) {
+      for (int k = 1; k < RP; ++k) {   // fixed order
+        const float4 o = red4[k * G + g];
+        t.x += o.x;
+        t.y += o.y;
+        t.z += o.z;
+        t.w += o.w;
+      }
+      reinterpret_cast<float4 *>(part + (int64_t)blockIdx.x * D)[g] = t;
+    }
+    return;
+  }
+  __shared__ float red[4][64];
+  const int q = tid >> 6;
   for (int32_t c0 = 0; c0 < D; c0 += 64) {
     const int32_t c = c0 + (tid & 63);
     float s0 = 0.f, s1 = 0.f;
