@@ -1,0 +1,88 @@
+"""GPU parity at the other benchmark configurations: the Clothing shape ranked with the item table
+cut into 1 / 2 / 4 / 8 shards (per-shard top-K with global ids, then the merge) against the
+unsharded ranking and the oracle, and the Sports shape through the whole MMFCN forward (4096-d
+image + 384-d text features) against the torch-CPU oracle at 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_oracle, graph_oracle, mmfcn_oracle
+from recommend_amd import ops, synth
+from recommend_amd.dist import item_range
+from recommend_amd.evaluator import pairs_to_csr, restrict_csr
+from recommend_amd.model import ModelFactory
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("mode", ["auto", "filter"])
+def test_clothing_shape_item_sharded_topk(mode):
+    d = synth.make_named("clothing")
+    rng = np.random.default_rng(2)
+    D = 64
+    # half-integer grid: plenty of exact score ties, so "lower id wins" is exercised across shards
+    ue = (np.round(rng.standard_normal((d.n_users, D)) * 2) / 8).astype(np.float32)
+    ie = (np.round(rng.standard_normal((d.n_items, D)) * 2) / 8).astype(np.float32)
+    tu, ti, _ = d.split(0)
+    ptr, cols = pairs_to_csr(tu, ti, d.n_users)
+    ued, ied = torch.from_numpy(ue).to(DEV), torch.from_numpy(ie).to(DEV)
+    for K in (5, 10, 20):
+        want_s, want_i = ops.score_topk(ued, ied, K, torch.from_numpy(ptr).to(DEV), torch.from_numpy(cols).to(DEV),
+                                        mode="exact")
+        if K == 20:
+            us = np.sort(rng.choice(d.n_users, 256, replace=False))
+            sub_ptr = np.concatenate([[0], np.cumsum(ptr[us + 1] - ptr[us])]).astype(np.int32)
+            sub_cols = np.concatenate([cols[ptr[u]:ptr[u + 1]] for u in us]).astype(np.int32)
+            o_s, o_i = eval_oracle.score_topk(ue[us], ie, K, sub_ptr, sub_cols)
+            np.testing.assert_array_equal(want_i.cpu().numpy()[us], o_i)
+            np.testing.assert_array_equal(want_s.cpu().numpy()[us], o_s)
+        for world in (1, 2, 4, 8):
+            ps, pi = [], []
+            for rank in range(world):
+                lo, hi = item_range(d.n_items, rank, world)
+                p2, c2 = restrict_csr(ptr, cols, lo, hi)
+                s, i = ops.score_topk(ued, ied[lo:hi], K, torch.from_numpy(p2).to(DEV), torch.from_numpy(c2).to(DEV),
+                                      item_id_offset=lo, mode=mode)
+                ps.append(s), pi.append(i)
+            ms, mi = ops.topk_merge(torch.stack(ps, 1), torch.stack(pi, 1), K)
+            assert torch.equal(mi, want_i), (K, world)
+            assert torch.equal(ms, want_s), (K, world)
+
+
+def test_sports_shape_forward_vs_oracle():
+    d = synth.make_named("sports")
+    U, I, D = d.n_users, d.n_items, 64
+    image, text = synth.make_features(I)[:2]
+    feats = {"image": torch.from_numpy(image), "text": torch.from_numpy(text)}
+
+    class C:
+        class data:
+            num_users, num_items = U, I
+        class model:
+            model_name = "MMFCN"
+            modal_num, emb_dim, layer_num, dropout = 2, D, 2, 0.0
+        class graph:
+            weight_feature = [None]
+            edge_weight_type, add_self_loops, normalize_adj = "uniform", True, True
+        class system:
+            device = DEV
+
+    torch.manual_seed(5)
+    model = ModelFactory.create_Model(C, {}, feats).to(DEV)
+    tu, ti, tr = d.split(0)
+    model.build_graph((tu, ti, tr))
+    model.creat_feature_weight()
+    model.eval()
+    with torch.no_grad():
+        out = model({})
+    src, dst, w = graph_oracle.build_coo_vectorized(tu, ti, tr, U, I, True)
+    wn, _ = graph_oracle.normalize(src, dst, w, U + I)
+    A = mmfcn_oracle.adjacency(src, dst, wn, U + I)
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    padded = [torch.cat([torch.zeros(U, f.shape[1]), f]) for f in feats.values()]
+    ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"],
+                                  model.embs.detach().cpu(), model.ks, model.alphas.detach().cpu(), 2, U)
+    for got, want in ((out["user_embeddings"], ue), (out["item_embeddings"], ie)):
+        err = (got.detach().cpu() - want).abs().max() / want.abs().max()
+        assert float(err) <= 1e-5, float(err)
