@@ -45,21 +45,35 @@ struct SplitN {
   bf16x8 h[NV / 8], m[NV / 8], l[NV / 8];   // element 8s + j is the lane's reduction index 8s + j
 };
 using Split3 = SplitN<32>;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Two values at a time, so that every step is one packed instruction or one per value: convert
+// (v_cvt_pk_bf16_f32), widen the two halves back (shift / mask), subtract (v_pk_add_f32):
+// 9 instructions per pair.
+__device__ __forceinline__ f32x2 widen(uint32_t pk) {
+  return f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xFFFF0000u)};
+}
 template <int NV>
 __device__ __forceinline__ void split3(const float (&x)[NV], SplitN<NV> &o) {
 #pragma unroll
-  for (int s4 = 0; s4 < NV / 8; ++s4)
+  for (int s4 = 0; s4 < NV / 8; ++s4) {
+    u32x4 hh, mm, ll;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = x[8 * s4 + j];
-      const __bf16 h = (__bf16)v;
-      const float r1 = v - (float)h;
-      const __bf16 m = (__bf16)r1;
-      const float r2 = r1 - (float)m;
-      o.h[s4][j] = h;
-      o.m[s4][j] = m;
-      o.l[s4][j] = (__bf16)r2;
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 v = {x[8 * s4 + 2 * q], x[8 * s4 + 2 * q + 1]};
+      const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+      const f32x2 r1 = v - widen(h);
+      const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+      const f32x2 r2 = r1 - widen(m);
+      hh[q] = h;
+      mm[q] = m;
+      ll[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
     }
+    o.h[s4] = __builtin_bit_cast(bf16x8, hh);
+    o.m[s4] = __builtin_bit_cast(bf16x8, mm);
+    o.l[s4] = __builtin_bit_cast(bf16x8, ll);
+  }
 }
 // acc += A (32 rows x this lane's NV reduction indices) * B^T in six bf16 products per step of 8;
 // the small terms first, the leading one last
@@ -201,8 +215,9 @@ __device__ __forceinline__ void load_w_row(const float *__restrict__ W, int row,
 }
 
 // ------------------------------------------------------------------ forward
+// (the plain layer is held to 256 registers per lane: two of its workgroups share a CU)
 template <bool DUAL, bool HAS_R>
-__global__ __launch_bounds__(256, 1) void dense_fwd_kernel(
+__global__ __launch_bounds__(256, (DUAL || HAS_R) ? 1 : 2) void dense_fwd_kernel(
     const float *__restrict__ X1, const float *__restrict__ W1, const float *__restrict__ X2,
     const float *__restrict__ W2, const float *__restrict__ b1, const float *__restrict__ b2,
     const float *__restrict__ alpha, float p_drop, uint64_t seed, const uint64_t *__restrict__ seed_step,
