@@ -190,6 +190,8 @@ def main():
         torch.cuda.synchronize()
         t_fwd = event_ms(lambda: model({}), 3)
     ue, ie = out["user_embeddings"].contiguous(), out["item_embeddings"].contiguous()
+    if not (bool(torch.isfinite(ue).all()) and bool(torch.isfinite(ie).all())):
+        raise RuntimeError("the model forward produced non-finite embeddings: nothing measured on them would mean anything")
 
     # ---------------------------------------------------------------- evaluation (the timed step)
     if world > 1:

@@ -98,3 +98,23 @@ def test_elec_full_ranking(elec):
     for k in (5, 10, 20):
         for m in METRICS:
             assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)
+
+
+def test_elec_projection_vs_fp64():
+    """The modality projection at the benchmark's item count and feature width, several fresh
+    calls (a kernel that reads its last K tiles before they have landed fails only now and then)."""
+    g = torch.Generator().manual_seed(4)
+    I, U, F = 63001, 192403, 4096
+    x = torch.randn(I, F, generator=g).to(DEV)
+    for rep in range(4):
+        w = (torch.randn(64, F, generator=g) / 64).to(DEV).requires_grad_(True)
+        b = torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+        y = ops.proj(x, w, b, U)
+        want = x.double() @ w.detach().double().T + b.detach().double()
+        assert torch.equal(y[:U], b.detach().expand(U, 64))
+        assert float((y[U:].double() - want).abs().max() / want.abs().max()) <= 1e-5, rep
+        go = torch.randn(U + I, 64, generator=g).to(DEV)
+        dw, db = torch.autograd.grad(y, [w, b], go)
+        want_dw = go[U:].double().T @ x.double()
+        assert float((dw.double() - want_dw).abs().max() / want_dw.abs().max()) <= 1e-5, rep
+        assert float((db.double() - go.double().sum(0)).abs().max() / go.double().sum(0).abs().max()) <= 1e-5, rep
