@@ -118,3 +118,40 @@ def test_elec_projection_vs_fp64():
         want_dw = go[U:].double().T @ x.double()
         assert float((dw.double() - want_dw).abs().max() / want_dw.abs().max()) <= 1e-5, rep
         assert float((db.double() - go.double().sum(0)).abs().max() / go.double().sum(0).abs().max()) <= 1e-5, rep
+
+
+@pytest.mark.parametrize("sparse_grad", [False, True])
+def test_elec_row_wise_layer_forward_backward_vs_fp64(sparse_grad):
+    """The fused row-wise layer at the benchmark's node count, several fresh calls, with a dense
+    upstream gradient and with one that is non-zero in a few hundred rows only (the all-zero tile
+    path of the backward kernel, as the first layers of the backward pass see it)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8)
+    n = 255404
+    for rep in range(3):
+        x = torch.randn(n, 64, generator=g)
+        w = torch.randn(64, 64, generator=g) / 8
+        b = torch.randn(64, generator=g)
+        go = torch.randn(n, 64, generator=g)
+        if sparse_grad:
+            keep = torch.zeros(n, 1)
+            keep[torch.randint(0, n, (768,), generator=g)] = 1
+            keep[-1] = 1                       # the partial last tile too
+            go = go * keep
+        for act in (True, False):
+            xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+            ad = torch.tensor([0.25], device=DEV, requires_grad=True) if act else None
+            y = ops.dense(xd, wd, bd, alpha=ad)
+            y.backward(go.to(DEV))
+            x6, w6, b6 = (t.double().requires_grad_(True) for t in (x, w, b))
+            a6 = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+            y6 = F.linear(x6, w6, b6)
+            if act:
+                y6 = F.prelu(y6, a6)
+            y6.backward(go.double())
+            pairs = [(y, y6), (xd.grad, x6.grad), (wd.grad, w6.grad), (bd.grad, b6.grad)]
+            if act:
+                pairs.append((ad.grad, a6.grad))
+            for got, want in pairs:
+                err = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
+                assert err <= 1e-5, (rep, act, err)
