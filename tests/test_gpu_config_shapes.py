@@ -1,6 +1,6 @@
 """GPU parity at the other benchmark configurations: the Clothing shape ranked with the item table
 cut into 1 / 2 / 4 / 8 shards (per-shard top-K with global ids, then the merge) against the
-unsharded ranking and the oracle, and the Sports shape through the whole MMFCN forward (4096-d
+unsharded ranking and the oracle, and the Sports and Elec shapes through the whole MMFCN forward (4096-d
 image + 384-d text features) against the torch-CPU oracle at 1e-5."""
 import numpy as np
 import pytest
@@ -50,8 +50,9 @@ def test_clothing_shape_item_sharded_topk(mode):
             assert torch.equal(ms, want_s), (K, world)
 
 
-def test_sports_shape_forward_vs_oracle():
-    d = synth.make_named("sports")
+@pytest.mark.parametrize("shape", ["sports", "elec"])
+def test_model_forward_vs_oracle_at_shape(shape):
+    d = synth.make_named(shape)
     U, I, D = d.n_users, d.n_items, 64
     image, text = synth.make_features(I)[:2]
     feats = {"image": torch.from_numpy(image), "text": torch.from_numpy(text)}
