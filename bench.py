@@ -227,7 +227,7 @@ def main():
     ms_topk = event_ms(topk_fn, max(3, args.steps))
     flop = 2.0 * U * n_loc * D
     tflops = flop / (ms_topk * 1e-3) / 1e12
-    filtered = U * n_loc >= (1 << 30) and D in (64, 128)   # what rk_score_topk_f32 decides
+    filtered = U * n_loc >= (1 << 29) and D in (64, 128)   # what rk_score_topk_f32 decides
     peak = MFMA_F16_PEAK_TFS if filtered else MFMA_F32_PEAK_TFS
     roofline = {"kernel": ("score_topk_kernel<fp16 filter> + merge + refine + exact fallback (one rk_score_topk_f32 call)"
                            if filtered else "score_topk_kernel (+topk_merge_kernel)"),

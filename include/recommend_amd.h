@@ -298,7 +298,7 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * user, re-scores those candidates with the exact chain, and runs the exact kernel only for users
  * whose result that procedure cannot certify (a candidate's fp16 score within the fp16 error bound
  * of the K-th exact score: ties at the K-th place, non-finite embeddings).
- * rk_score_topk_f32 picks between the two by size (the filter pays off from ~10^9 scores).
+ * rk_score_topk_f32 picks between the two by size (the filter pays off from ~5*10^8 scores).
  * All take the same workspace. */
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D,
                               int32_t K);

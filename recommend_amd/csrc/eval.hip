@@ -447,10 +447,10 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
                       int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
                       int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
                       size_t ws_bytes, void *stream) {
-  // The filter's dozen launches cost about a millisecond whatever the size; below ~10^9 scores
-  // the exact kernel alone is faster (measured: 1.4e8 scores 0.46 ms exact / 1.2 ms filtered,
-  // 1.2e10 scores 14.6 / 4.8 ms).
-  if ((int64_t)n_users * n_items < ((int64_t)1 << 30))
+  // The filter's dozen launches cost about a millisecond whatever the size; measured crossover:
+  // 19k x 7k (1.4e8 scores) exact 0.46 ms / filter 0.96 ms, 36k x 18k (6.5e8) 1.41 / 0.97,
+  // 39k x 23k (9.1e8) 1.61 / 1.05.  From 2^29 scores up the filter wins.
+  if ((int64_t)n_users * n_items < ((int64_t)1 << 29))
     return rk_score_topk_exact_f32(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
                                    out_scores, out_ids, ws, ws_bytes, stream);
   return rk_score_topk_filtered_f32(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
