@@ -1,5 +1,7 @@
+"""Probe: exact kernel against the candidate filter at the Baby / Sports / Clothing shapes (where the
+automatic choice of rk_score_topk_f32 switches)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from recommend_amd import ops, synth
 from recommend_amd.evaluator import pairs_to_csr
