@@ -155,3 +155,35 @@ def test_elec_row_wise_layer_forward_backward_vs_fp64(sparse_grad):
             for got, want in pairs:
                 err = float((got.detach().cpu().double() - want.detach()).abs().max() / want.detach().abs().max())
                 assert err <= 1e-5, (rep, act, err)
+
+
+def test_elec_row_wise_layer_dropout_mask_is_the_same_forward_and_backward():
+    """At the benchmark's node count, with dropout on: the mask read off the forward output
+    reproduces the backward pass in float64, i.e. both kernels drew the same mask everywhere."""
+    g = torch.Generator().manual_seed(12)
+    n, p = 255404, 0.3
+    x = torch.randn(n, 64, generator=g)
+    w = torch.randn(64, 64, generator=g) / 8
+    b = torch.randn(64, generator=g)
+    go = torch.randn(n, 64, generator=g)
+    z = x.double() @ w.double().T + b.double()
+    # Among 16 M pre-activations a few cancel to (almost) zero: there a kept element cannot be told
+    # from a dropped one by looking at y, and the sign of the fp32 z is not the float64 one.  Those
+    # elements get no upstream gradient, so that nothing below depends on them.
+    go[z.abs() < 1e-5] = 0.0
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    ad = torch.tensor([0.25], device=DEV, requires_grad=True)
+    y = ops.dense(xd, wd, bd, alpha=ad, p=p, seed=77)
+    y.backward(go.to(DEV))
+    act = torch.where(z > 0, z, 0.25 * z)
+    keep = (y.detach().cpu() != 0).double()
+    assert abs(float(keep.mean()) - (1 - p)) < 2e-3
+    want_y = act * keep / (1 - p)
+    assert float((y.detach().cpu().double() - want_y).abs().max() / want_y.abs().max()) <= 1e-5
+    # not one row or column is dropped or kept as a whole
+    assert 0.6 < float(keep.mean(0).min()) and float(keep.mean(0).max()) < 0.8
+    dz = go.double() * keep / (1 - p) * torch.where(z > 0, 1.0, 0.25)
+    for got, want in ((xd.grad, dz @ w.double()), (wd.grad, dz.T @ x.double()), (bd.grad, dz.sum(0)),
+                      (ad.grad, (go.double() * keep / (1 - p) * torch.where(z > 0, 0.0, 1.0) * z).sum().reshape(1))):
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err <= 1e-5, err
