@@ -84,27 +84,31 @@ __device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, c
   return skip == nullptr || skip[row_out] == 0;   // flagged rows of out are already final
 }
 
+// Candidates of the four rows of a workgroup: scores and ids of row w at [2 * n * w, ...).  Sized by
+// the launch (n entries per row, not MERGE_MAX): a merge lives on the number of rows in flight.
+extern __shared__ float merge_lds[];
+
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t n, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
     int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  __shared__ float cs[4][MERGE_MAX];
-  __shared__ int32_t ci[4][MERGE_MAX];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  float *cs_w = merge_lds + (size_t)wave * 2 * n;
+  int32_t *ci_w = reinterpret_cast<int32_t *>(cs_w + n);
   int32_t pos, user;
   if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
   for (int c = lane; c < n; c += kWave) {
-    cs[wave][c] = scores[(int64_t)pos * n + c];
-    ci[wave][c] = ids[(int64_t)pos * n + c];
+    cs_w[c] = scores[(int64_t)pos * n + c];
+    ci_w[c] = ids[(int64_t)pos * n + c];
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
   for (int c = lane; c < n; c += kWave) {
-    const float sc = cs[wave][c];
-    const int32_t ic = ci[wave][c];
+    const float sc = cs_w[c];
+    const int32_t ic = ci_w[c];
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += beats(cs[wave][j], ci[wave][j], j, sc, ic, c) ? 1 : 0;
+    for (int j = 0; j < n; ++j) rank += beats(cs_w[j], ci_w[j], j, sc, ic, c) ? 1 : 0;
     if (rank < K) {
       out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
       out_id[(int64_t)user * K + rank] = ic;
@@ -121,21 +125,21 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
     int32_t n_users, int32_t P, int32_t Kin, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
     int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  __shared__ float cs[4][MERGE_MAX];
-  __shared__ int32_t ci[4][MERGE_MAX];
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int n = P * Kin;
+  float *cs_w = merge_lds + (size_t)wave * 2 * n;
+  int32_t *ci_w = reinterpret_cast<int32_t *>(cs_w + n);
   int32_t pos, user;
   if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
   for (int c = lane; c < n; c += kWave) {
-    cs[wave][c] = scores[(int64_t)pos * n + c];
-    ci[wave][c] = ids[(int64_t)pos * n + c];
+    cs_w[c] = scores[(int64_t)pos * n + c];
+    ci_w[c] = ids[(int64_t)pos * n + c];
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
   for (int c = lane; c < n; c += kWave) {
-    const float sc = cs[wave][c];
-    const int32_t ic = ci[wave][c];
+    const float sc = cs_w[c];
+    const int32_t ic = ci_w[c];
     const int own = c / Kin;
     int rank = c - own * Kin;
     for (int q = 0; q < P; ++q) {
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
       int lo = 0, hi = Kin;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1, j = q * Kin + mid;
-        if (beats(cs[wave][j], ci[wave][j], j, sc, ic, c))
+        if (beats(cs_w[j], ci_w[j], j, sc, ic, c))
           lo = mid + 1;
         else
           hi = mid;
@@ -282,11 +286,12 @@ int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_
                (long long)P * Kin, MERGE_MAX);
   RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
   const int grid = (int)rk::ceil_div(n_users, 4);
+  const size_t lds = (size_t)4 * 2 * P * Kin * sizeof(float);
   if (sorted_lists)
-    topk_merge_sorted_kernel<<<grid, 256, 0, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
+    topk_merge_sorted_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
                                                    sel.cap, rows_per_user, out_scores, out_ids);
   else
-    topk_merge_kernel<<<grid, 256, 0, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
+    topk_merge_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
                                             sel.cap, rows_per_user, out_scores, out_ids);
   RK_CHECK_LAUNCH("topk_merge_kernel");
   return RK_OK;
