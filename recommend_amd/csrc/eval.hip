@@ -235,13 +235,30 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-__global__ void rank_metrics_final_kernel(const double *__restrict__ part, int32_t n_part,
-                                          int32_t nk, double denom, float *__restrict__ out,
-                                          double *__restrict__ sums_out) {
-  const int i = threadIdx.x;  // one thread per (k, metric), sequential over blocks
-  if (i >= nk * 6) return;
+// Sum of the per-workgroup partials in a fixed order: 16 threads per (k, metric) take the blocks
+// b = q, q + 16, ... in ascending order and thread q = 0 adds the 16 sums in order (one thread
+// walking all blocks took 180 us for the 752 blocks of 192k users).
+__global__ __launch_bounds__(1024) void rank_metrics_final_kernel(const double *__restrict__ part, int32_t n_part,
+                                                                  int32_t nk, double denom, float *__restrict__ out,
+                                                                  double *__restrict__ sums_out) {
+  __shared__ double red[16][64];
+  const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+  static_assert(MAXK * 6 <= 64, "one lane per (k, metric)");
+  double s0 = 0.0, s1 = 0.0;
+  if (i < nk * 6) {
+    int32_t b = q;
+    for (; b + 16 < n_part; b += 32) {
+      s0 += part[(int64_t)b * (MAXK * 6) + i];
+      s1 += part[(int64_t)(b + 16) * (MAXK * 6) + i];
+    }
+    if (b < n_part) s0 += part[(int64_t)b * (MAXK * 6) + i];
+  }
+  red[q][i] = s0 + s1;
+  __syncthreads();
+  if (q != 0 || i >= nk * 6) return;
   double s = 0.0;
-  for (int32_t b = 0; b < n_part; ++b) s += part[(int64_t)b * (MAXK * 6) + i];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][i];
   if (sums_out) sums_out[i] = s;
   out[i] = (float)(s / denom);
 }
@@ -583,7 +600,7 @@ int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_str
   rank_metrics_kernel<<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk,
                                            kmax, discounts, (double *)ws);
   RK_CHECK_LAUNCH("rank_metrics_kernel");
-  rank_metrics_final_kernel<<<1, 64, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
+  rank_metrics_final_kernel<<<1, 1024, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
                                                out, sums_out);
   RK_CHECK_LAUNCH("rank_metrics_final_kernel");
   return RK_OK;
