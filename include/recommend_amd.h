@@ -243,6 +243,24 @@ int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
                    const float *loss_out, const float *gout, float *dU,
                    float *dI, void *stream);
 
+/* rk_bpr_fwd_f32 for callers that cannot allocate device memory or hand over a
+ * workspace (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and
+ * the same result bits as rk_bpr_fwd_f32 without ws / ws_bytes: the partial sums
+ * of the workgroups go to a device array built into the library (32 KiB per GPU,
+ * held until the process ends), whose address is looked up once per device on the
+ * first call there.  B <= rk_bpr_fwd_noalloc_max_batch() (65,536 samples), otherwise
+ * RK_ERR_UNSUPPORTED.  No hipMalloc / hipFree happens in the call.  All calls on one
+ * GPU share the array: two calls in flight on different streams of one GPU race
+ * (calls on one stream are ordered and safe; nothing needs clearing between them). */
+int64_t rk_bpr_fwd_noalloc_max_batch(void);
+int rk_bpr_fwd_noalloc_f32(const float *U, const float *I, int32_t D,
+                           const int64_t *users, const int64_t *pos, int64_t *neg,
+                           int64_t B, int32_t R, const float *mask,
+                           const int32_t *neg_rank, const int32_t *pos_ptr,
+                           const int32_t *pos_items, int32_t n_items,
+                           float *x_out, float *loss_out, void *stream);
+
 /* ---- L2: the other pairwise losses over the same gather-dot --------------- */
 /* Same arguments as rk_bpr_fwd_f32 / rk_bpr_bwd_f32 plus `mode`:
  *   RK_LOSS_BPR          mean(-logsigmoid(x))                 (= rk_bpr_*)

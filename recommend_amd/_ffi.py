@@ -76,6 +76,9 @@ SIGNATURES = {
     "rk_bpr_ws_bytes": (c_size_t, [c_int64, c_int32]),
     "rk_bpr_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32,
                                  P, P, P, c_size_t, P]),
+    "rk_bpr_fwd_noalloc_max_batch": (c_int64, []),
+    "rk_bpr_fwd_noalloc_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32,
+                                         P, P, P]),
     "rk_bpr_bwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, P, P, P]),
     "rk_rank_loss_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32, c_int32,
                                        P, P, P, c_size_t, P]),

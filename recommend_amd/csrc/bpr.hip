@@ -10,6 +10,8 @@
 // coalesced 256-byte read per gathered row.  The per-sample losses are reduced
 // in a fixed order (group -> block -> final block), never with float atomics,
 // so the forward value is run-to-run deterministic.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -254,6 +256,35 @@ __global__ __launch_bounds__(256) void bpr_scores_bwd_kernel(
 
 }  // namespace
 
+// ---- the forward pass for callers that cannot allocate -------------------------------------
+// The per-workgroup partial sums live in a file-scope device array instead of a caller
+// workspace.  kNoAllocMaxBatch bounds the batch; each GPU the library runs on holds its own
+// copy of the array (kNoAllocMaxBatch / SPB * 2 + 2 floats = 32 KiB + 8 B) for the life of the
+// process.  `scratch` is a host-side stand-in, not a device address: host code only ever uses
+// the per-device pointer that hipGetSymbolAddress returned.
+constexpr int64_t kNoAllocMaxBatch = 65536;
+constexpr int kNoAllocMaxDevices = 64;
+static __device__ __align__(256) float scratch[2 * (kNoAllocMaxBatch / SPB) + 2];
+static float *g_scratch_ptr[kNoAllocMaxDevices];   // per device, filled on the first call there
+static std::mutex g_scratch_mutex;
+
+static int scratch_for_current_device(float **out) {
+  int dev = -1;
+  RK_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kNoAllocMaxDevices)
+    return rk::fail(RK_ERR_UNSUPPORTED, "device ordinal %d beyond the %d this entry point tracks", dev,
+                    kNoAllocMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void *p = nullptr;
+    RK_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return rk::fail(RK_ERR_HIP, "hipGetSymbolAddress returned a null scratch address");
+    g_scratch_ptr[dev] = static_cast<float *>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return RK_OK;
+}
+
 extern "C" {
 
 int rk_bpr_scores_fwd_f32(const float *pos, const float *neg, int64_t B, int32_t R,
@@ -322,6 +353,28 @@ int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
                    float *loss_out, void *ws, size_t ws_bytes, void *stream) {
   return rk_rank_loss_fwd_f32(U, I, D, users, pos, neg, B, R, mask, neg_rank, pos_ptr, pos_items,
                               n_items, kModeLogSigmoid, x_out, loss_out, ws, ws_bytes, stream);
+}
+
+int64_t rk_bpr_fwd_noalloc_max_batch(void) { return kNoAllocMaxBatch; }
+
+int rk_bpr_fwd_noalloc_f32(const float *U, const float *I, int32_t D, const int64_t *users,
+                           const int64_t *pos, int64_t *neg, int64_t B, int32_t R,
+                           const float *mask, const int32_t *neg_rank, const int32_t *pos_ptr,
+                           const int32_t *pos_items, int32_t n_items, float *x_out,
+                           float *loss_out, void *stream) {
+  if (B > kNoAllocMaxBatch)
+    return rk::fail(RK_ERR_UNSUPPORTED,
+                    "rk_bpr_fwd_noalloc_f32: batch of %lld samples exceeds the built-in scratch (%lld); "
+                    "use rk_bpr_fwd_f32 with a caller workspace",
+                    (long long)B, (long long)kNoAllocMaxBatch);
+  float *part = nullptr;
+  const int rc = scratch_for_current_device(&part);
+  if (rc != RK_OK) return rc;
+  // every partial the final reduction reads is written by this call's forward kernel first, so
+  // nothing left in the array by an earlier (larger) call is ever read
+  return rk_rank_loss_fwd_f32(U, I, D, users, pos, neg, B, R, mask, neg_rank, pos_ptr, pos_items,
+                              n_items, kModeLogSigmoid, x_out, loss_out, part,
+                              sizeof(float) * (2 * (kNoAllocMaxBatch / SPB) + 2), stream);
 }
 
 int rk_rank_loss_bwd_f32(const float *U, const float *I, int32_t D,
