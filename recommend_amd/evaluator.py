@@ -29,7 +29,7 @@ def pairs_to_csr(rows, cols, n_rows):
     key = np.unique(rows * width + cols)
     r, c = key // width, key % width
     ptr = np.zeros(n_rows + 1, np.int64)
-    np.add.at(ptr, r + 1, 1)
+    ptr[1:] = np.bincount(r, minlength=n_rows)
     return np.cumsum(ptr).astype(np.int32), c.astype(np.int32)
 
 

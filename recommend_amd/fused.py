@@ -1,10 +1,11 @@
 """Routes `dropout(active(linear(x)))` compositions of the reference's blocks to
-the fused node-wise layer kernel (rk_dense_*) when the modules are the ones the
-MMFCN blocks use (nn.Linear 64 -> 64, one-slope PReLU, nn.Dropout) and the
-tensors live on the GPU; any other combination of callables runs as given."""
+the fused node-wise layer kernel (rk_dense_*).  The modules must be the ones the
+MMFCN blocks use (square nn.Linear of a built width, one-slope PReLU, nn.Dropout)
+and the tensors must live on the GPU: anything else raises, there is no second
+implementation behind these calls."""
 import torch.nn as nn
 
-from . import ops
+from . import _ffi, ops
 
 
 def prelu_slope(active):
@@ -19,14 +20,20 @@ def prelu_slope(active):
     return p
 
 
-def can_fuse(linear, x, active=None, dropout=None):
-    if not isinstance(linear, nn.Linear) or not ops.dense_supported(x, linear.weight):
-        return False
+def check_fusable(linear, x, active=None, dropout=None):
+    """Raise unless the composition is one the layer kernels compute."""
+    if not x.is_cuda:
+        raise _ffi.RkError(_ffi.RK_ERR_NODEV, "the node-wise layers run only on a HIP device; there is no CPU fallback")
+    if not isinstance(linear, nn.Linear):
+        raise _ffi.RkError(_ffi.RK_ERR_UNSUPPORTED, f"node-wise layer: {type(linear).__name__} is not an nn.Linear")
+    if not ops.dense_supported(x, linear.weight):
+        raise _ffi.RkError(_ffi.RK_ERR_UNSUPPORTED,
+                           f"node-wise layer {tuple(x.shape)} x {tuple(linear.weight.shape)}^T: built for square "
+                           f"layers of width {ops.DENSE_WIDTHS}")
     if active is not None and prelu_slope(active) is None:
-        return False
+        raise _ffi.RkError(_ffi.RK_ERR_UNSUPPORTED, "node-wise layer: the activation must be a one-slope PReLU")
     if dropout is not None and not isinstance(dropout, nn.Dropout):
-        return False
-    return True
+        raise _ffi.RkError(_ffi.RK_ERR_UNSUPPORTED, "node-wise layer: the dropout must be an nn.Dropout")
 
 
 def drop_p(dropout):
@@ -35,19 +42,13 @@ def drop_p(dropout):
 
 def linear_act(linear, x, active=None, dropout=None, residual=None):
     """dropout(active(linear(x))) [+ residual]"""
-    if can_fuse(linear, x, active, dropout):
-        return ops.dense(x, linear.weight, linear.bias, alpha=prelu_slope(active), p=drop_p(dropout),
-                         residual=residual)
-    y = linear(x)
-    if active is not None:
-        y = active(y)
-    if dropout is not None:
-        y = dropout(y)
-    return y if residual is None else residual + y
+    check_fusable(linear, x, active, dropout)
+    return ops.dense(x, linear.weight, linear.bias, alpha=prelu_slope(active), p=drop_p(dropout),
+                     residual=residual)
 
 
 def linear_sum(linear1, x1, linear2, x2):
     """linear1(x1) + linear2(x2)"""
-    if can_fuse(linear1, x1) and can_fuse(linear2, x2):
-        return ops.dense(x1, linear1.weight, linear1.bias, x2=x2, weight2=linear2.weight, bias2=linear2.bias)
-    return linear1(x1) + linear2(x2)
+    check_fusable(linear1, x1)
+    check_fusable(linear2, x2)
+    return ops.dense(x1, linear1.weight, linear1.bias, x2=x2, weight2=linear2.weight, bias2=linear2.bias)

@@ -91,13 +91,7 @@ class TEST(nn.Module):
     def forward(self, g, Xs, embs, ks, alphas):
         modal_features = [self.MGCNs[i](g, Xs[i], embs[i], ks[i]) for i in range(self.modal_num)]
         # sum_m softmax(alphas)_m * F_m (out_Layer.py:52-54) without stacking the modalities
-        if ops.modal_sum_supported(modal_features, alphas):
-            return ops.modal_sum(modal_features, alphas)
-        new_alphas = torch.softmax(alphas, dim=0)
-        out = modal_features[0] * new_alphas[0]
-        for i in range(1, self.modal_num):
-            out = out + modal_features[i] * new_alphas[i]
-        return out
+        return ops.modal_sum(modal_features, alphas)
 
 
 class _ItemProjection(nn.Module):
@@ -157,7 +151,8 @@ class TESTModel(nn.Module):
         # its autograd nodes, and the stream they were created on, alive across steps)
         # a plain tensor, not a Parameter: assigning a Parameter would register it, and the reference's
         # first table is replaced as a submodule (Main_Model.py:98) and so is never handed to the optimizer
-        self._first_emb = nn.Embedding(self.num_nodes, emb_dim, device=device).weight.detach().requires_grad_(True)
+        # (and frozen: no optimizer ever sees it, so a gradient would only be computed, accumulated and never read)
+        self._first_emb = nn.Embedding(self.num_nodes, emb_dim, device=device).weight.detach()
 
         self.test = TEST(modal_num=self.modal_num, emb_num=emb_dim, layer_num=layer_num,
                          dropout=dropout)

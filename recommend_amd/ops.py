@@ -89,9 +89,11 @@ class CsrMatrix:
 
     LONG_THRESH = 64
 
-    def __init__(self, rowptr, idx, eid, device):
+    def __init__(self, rowptr, idx, eid, device, n_cols=None):
         self.n_rows = int(rowptr.shape[0] - 1)
         self.nnz = int(idx.shape[0])
+        # rows of h the kernel may read: callers hand over h with at least this many rows
+        self.n_cols = int(n_cols) if n_cols is not None else (int(np.max(idx)) + 1 if self.nnz else 0)
         self.device = torch.device(device)
         pl = spmm_plan_host(rowptr, self.LONG_THRESH)
         # empty arrays are padded to one element so that no NULL pointer reaches the library
@@ -142,8 +144,14 @@ def spmm_raw(mat, h, h0=None, alpha=0.0, beta=1.0, out=None):
     if mat.val is None:
         raise ValueError("sparse matrix has no edge values yet")
     h = _f32c(h)
-    if h.dim() != 2 or h.shape[0] < 0:
-        raise ValueError("h must be [n_nodes, D]")
+    if h.dim() != 2 or h.shape[0] < mat.n_cols:
+        raise ValueError(f"h must be [n_nodes >= {mat.n_cols}, D]: the operand gathers rows up to {mat.n_cols - 1}, "
+                         f"h has shape {tuple(h.shape)}")
+    if h0 is not None and (h0.dim() != 2 or h0.shape[0] < mat.n_rows or h0.shape[1] != h.shape[1]):
+        raise ValueError(f"h0 must be [n_rows >= {mat.n_rows}, {h.shape[1]}], got {tuple(h0.shape)}")
+    if out is not None and (not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous()
+                            or out.shape[0] < mat.n_rows or out.shape[1] != h.shape[1]):
+        raise ValueError("out must be a contiguous fp32 CUDA tensor [n_rows, D]")
     D = h.shape[1]
     if out is None:
         out = torch.empty((mat.n_rows, D), dtype=torch.float32, device=h.device)
@@ -339,8 +347,12 @@ def set_dropout_step_tensor(t):
     _dropout_step[t.device] = t
 
 
+DENSE_WIDTHS = (64,)   # K = D of the built rk_dense_* kernels
+
+
 def dense_supported(x, weight):
-    return x.is_cuda and x.dim() == 2 and tuple(weight.shape) == (64, 64) and x.shape[1] == 64
+    return (x.is_cuda and x.dim() == 2 and weight.shape[0] == weight.shape[1] and weight.shape[0] in DENSE_WIDTHS
+            and x.shape[1] == weight.shape[1])
 
 
 class _Dense(torch.autograd.Function):
@@ -452,6 +464,10 @@ def modal_sum_supported(feats, alphas):
 
 def modal_sum(feats, alphas):
     """sum_m softmax(alphas)_m * feats[m] (model/test/out_Layer.py:52-54) in one pass."""
+    if not modal_sum_supported(feats, alphas):
+        raise _ffi.RkError(_ffi.RK_ERR_UNSUPPORTED,
+                           f"modality-weighted sum of {len(feats)} matrices: built for 1..4 equal-shaped fp32 CUDA "
+                           "matrices (element count a multiple of 4) and one weight per matrix")
     return _ModalSum.apply(alphas, *feats)
 
 

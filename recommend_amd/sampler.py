@@ -25,7 +25,7 @@ def build_user_csr(users, items, n_users):
     u = key // m
     it = (key % m).astype(np.int32)
     ptr_ = np.zeros(n_users + 1, np.int64)
-    np.add.at(ptr_, u + 1, 1)
+    ptr_[1:] = np.bincount(u, minlength=n_users)
     return np.cumsum(ptr_).astype(np.int32), it
 
 
@@ -39,6 +39,17 @@ class NegativeSampler:
         self.pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int32)
         self.pos_items = np.ascontiguousarray(pos_items, dtype=np.int32)
         self.n_items = int(n_items)
+        # The reference draws from all_items = the ids that OCCUR in the interaction table
+        # (data/graph_data_loader.py:173); this sampler ranks candidates over range(n_items).  The
+        # two agree (and the random stream stays the reference's) only if every id occurs.
+        present = np.zeros(self.n_items, bool)
+        present[self.pos_items[(self.pos_items >= 0) & (self.pos_items < self.n_items)]] = True
+        if not present.all():
+            missing = np.flatnonzero(~present)
+            raise ValueError(
+                f"{missing.size} item ids below n_items={self.n_items} never occur in the interaction table "
+                f"(first: {missing[:5].tolist()}); the reference samples negatives from the ids that occur, "
+                "so its candidate lists and random stream differ from range(n_items): remap item ids densely")
         self.neg_ratio = int(neg_ratio)
         self.state = np.zeros(625, np.uint32)
         self.seed(seed)

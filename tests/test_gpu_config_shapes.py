@@ -119,6 +119,9 @@ def test_elec_training_step_gradients_vs_oracle():
     model.build_graph((tu, ti, tr))
     model.creat_feature_weight()
     model.train()
+    # the table the network reads is frozen in training runs (no optimizer holds it); its gradient
+    # is asked for here so that the dX path of the embedding branch is checked as well
+    model._first_emb.requires_grad_(True)
     rng = np.random.default_rng(1)
     sel = rng.choice(len(tu), 256, replace=False)
     batch = {"user_ids": torch.from_numpy(tu[sel]).to(DEV), "item_ids": torch.from_numpy(ti[sel]).to(DEV),

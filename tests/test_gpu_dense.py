@@ -119,11 +119,19 @@ def test_module_routing_matches_unfused_modules():
     torch.testing.assert_close(fused.linear_act(lin, x, act, dr), dr(act(lin(x))), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(fused.linear_act(lin, x, None, dr, residual=x2), x2 + lin(x), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(fused.linear_sum(lin, x, lin2, x2), lin(x) + lin2(x2), rtol=1e-5, atol=1e-5)
-    # shapes the kernel is not built for run as plain modules
+    # shapes the kernels are not built for raise: there is no second implementation behind them
+    from recommend_amd import _ffi
     lin3 = torch.nn.Linear(48, 64).to(DEV)
     x3 = torch.randn(10, 48, device=DEV)
-    assert not fused.can_fuse(lin3, x3)
-    torch.testing.assert_close(fused.linear_act(lin3, x3, act, dr), act(lin3(x3)))
+    with pytest.raises(_ffi.RkError) as e:
+        fused.linear_act(lin3, x3, act, dr)
+    assert e.value.code == _ffi.RK_ERR_UNSUPPORTED
+    with pytest.raises(_ffi.RkError) as e:
+        fused.linear_act(lin.cpu(), x.cpu(), act.cpu(), dr)
+    assert e.value.code == _ffi.RK_ERR_NODEV
+    lin.to(DEV), act.to(DEV)
+    with pytest.raises(_ffi.RkError):
+        ops.modal_sum([torch.randn(8, 64, device=DEV) for _ in range(5)], torch.randn(5, device=DEV))
 
 
 @pytest.mark.parametrize("M,n", [(2, 1000), (3, 255404), (1, 7), (4, 64)])
