@@ -325,12 +325,13 @@ def main():
             cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \
                                   "oracle's MMFCN at the same shape, no warm-up step"
 
-    # N > 1: one row-sharded propagation hop (all-gather of the layer over RCCL + local SpMM on the
-    # rank's rows), outside the timed region; the slowest rank counts.
-    sharded_hop = None
+    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
+    # (a) one propagation hop (all-gather of the layer over RCCL + local SpMM on the rank's rows),
+    # (b) the whole MMFCN training step with rows and batch sharded (recommend_amd.dist_train).
+    sharded_hop = sharded_train = None
     if world > 1:
+        from recommend_amd.dist import RowShardedGraph, all_reduce_tensor
         try:
-            from recommend_amd.dist import RowShardedGraph, all_reduce_tensor
             wn = gc.graph.edata[gc.weight].detach().cpu().numpy()
             rg = RowShardedGraph(gc.graph.src, gc.graph.dst, wn, N, rank, world, device=dev)
             h_loc = torch.randn(rg.hi - rg.lo, D, device=dev)
@@ -341,8 +342,46 @@ def main():
             sharded_hop = {"ms_per_hop": round(float(t), 5), "rows_per_rank": rg.block,
                            "all_gather_bytes_total": N * D * 4,
                            "note": "all-gather of the layer + SpMM on this rank's rows; max over ranks"}
+            del rg
         except Exception as e:  # reported, never fatal for the headline line
             sharded_hop = {"error": repr(e)}
+        try:
+            from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
+            torch.manual_seed(42)
+            smodel = ShardedTESTModel(cfg, {}, feats, rank, world).to(dev)
+            node_i = ti + U
+            mine = ((tu >= smodel.lo) & (tu < smodel.hi)) | ((node_i >= smodel.lo) & (node_i < smodel.hi))
+            idx = np.flatnonzero(mine)
+            smodel.build_graph((tu[idx], ti[idx], tr[idx]), index=idx, n_total=len(tu))
+            smodel.creat_feature_weight()
+            smodel.train()
+            sopt = torch.optim.Adam(smodel.parameters(), lr=1e-3)
+            sstep = ShardedTrainStep(smodel, sopt, gather_dot_bpr_loss, max_grad_norm=1.0)
+            Bg = BATCH[args.shape] * world          # weak scaling: the per-GPU batch is the preset's
+            gen = np.random.default_rng(7)
+            def global_batch():
+                sel = gen.integers(0, len(tu), Bg)
+                return {"user_ids": torch.from_numpy(tu[sel]).to(dev), "item_ids": torch.from_numpy(ti[sel]).to(dev),
+                        "neg_items": torch.from_numpy(gen.integers(0, I, (Bg, 1))).to(dev)}
+            batches = [global_batch() for _ in range(8)]
+            for b in batches[:3]:
+                sstep(b)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            n_timed = 10
+            for i in range(n_timed):
+                last = sstep(batches[i % len(batches)])
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / n_timed * 1e3], dtype=torch.float64, device=dev)
+            all_reduce_tensor(t, dist.ReduceOp.MAX)
+            sharded_train = {"ms_per_train_step": round(float(t), 4), "global_batch": Bg, "steps_timed": n_timed,
+                             "last_loss": round(float(last), 6),
+                             "layout": f"rows of the graph and of every node matrix over {world} ranks, batch split; "
+                                       "eager launches (no captured graph: the step contains collectives)"}
+        except Exception as e:
+            sharded_train = {"error": repr(e)}
     if rank == 0:
         line = {
             "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
@@ -361,6 +400,8 @@ def main():
         }
         if sharded_hop is not None:
             line["row_sharded_hop"] = sharded_hop
+        if sharded_train is not None:
+            line["row_sharded_train_step"] = sharded_train
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -91,6 +91,22 @@ int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
                          int32_t n_nodes, float *sqrt_in_w, float *w_norm_coo,
                          void *stream);
 
+/* The two halves of rk_sym_normalize_f32 for a graph whose rows are spread over several GPUs
+ * (every GPU holds the destination rows [row_offset, row_offset + n_rows) of the CSR, columns
+ * global, eid / w_coo local to its own edge list):
+ *   rk_in_weight_sqrt_f32: sqrt_in_w_rows[v] = sqrt(max(sum of the row's w, 1e-12)),
+ *     graph_constructor.py:177-178, for the local rows;
+ *   rk_sym_scale_rows_f32: w_norm[e] = w[e] / (sqrt_in_w[col] * sqrt_in_w[row_offset + v]),
+ *     graph_constructor.py:186, with sqrt_in_w the vector over ALL nodes (the local pieces
+ *     gathered by the caller).  The transposed block (rows = sources) takes the same call. */
+int rk_in_weight_sqrt_f32(const int32_t *rowptr, const int32_t *eid,
+                          const float *w_coo, int32_t n_rows,
+                          float *sqrt_in_w_rows, void *stream);
+int rk_sym_scale_rows_f32(const int32_t *rowptr, const int32_t *col,
+                          const int32_t *eid, const float *w_coo, int32_t n_rows,
+                          int32_t row_offset, const float *sqrt_in_w,
+                          float *w_norm_coo, void *stream);
+
 /* Degree normalisation of the live models (model/sgrec/graph.py:123-135,
  * model/mig/mgdcf.py:106-126): w_e = deg_in[src]^-0.5 * deg_in[dst]^-0.5 with
  * deg_in counted from the CSR (rows = dst). */

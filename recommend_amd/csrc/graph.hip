@@ -50,13 +50,13 @@ __global__ void sym_norm_kernel(const int32_t *__restrict__ rowptr,
                                 const int32_t *__restrict__ col,
                                 const int32_t *__restrict__ eid,
                                 const float *__restrict__ w_coo,
-                                const float *__restrict__ sq, int32_t n,
+                                const float *__restrict__ sq, int32_t n, int32_t row_offset,
                                 float *__restrict__ w_norm) {
   const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
   const int32_t lo = rowptr[v], hi = rowptr[v + 1];
   if (hi - lo > kLongRow) return;
-  const float sv = sq[v];
+  const float sv = sq[v + row_offset];
   for (int32_t p = lo; p < hi; ++p) {
     const int32_t e = eid[p];
     w_norm[e] = w_coo[e] / (sq[col[p]] * sv);
@@ -68,13 +68,13 @@ __global__ __launch_bounds__(256) void sym_norm_long_kernel(const int32_t *__res
                                                             const int32_t *__restrict__ eid,
                                                             const float *__restrict__ w_coo,
                                                             const float *__restrict__ sq, int32_t n,
-                                                            float *__restrict__ w_norm) {
+                                                            int32_t row_offset, float *__restrict__ w_norm) {
   const int32_t v = blockIdx.x * 4 + threadIdx.x / kWave;
   const int lane = threadIdx.x % kWave;
   if (v >= n) return;
   const int32_t lo = rowptr[v], hi = rowptr[v + 1];
   if (hi - lo <= kLongRow) return;
-  const float sv = sq[v];
+  const float sv = sq[v + row_offset];
   for (int32_t p = lo + lane; p < hi; p += kWave) {
     const int32_t e = eid[p];
     w_norm[e] = w_coo[e] / (sq[col[p]] * sv);
@@ -113,9 +113,45 @@ __global__ void gather_kernel(const float *__restrict__ src,
   if (i < n) out[i] = src[idx[i]];
 }
 
+int launch_in_weight_sqrt(const int32_t *rowptr, const int32_t *eid, const float *w_coo, int32_t n_rows,
+                          float *sq_rows, hipStream_t st) {
+  in_weight_sqrt_kernel<<<(int)rk::ceil_div(n_rows, 256), 256, 0, st>>>(rowptr, eid, w_coo, n_rows, sq_rows);
+  RK_CHECK_LAUNCH("in_weight_sqrt_kernel");
+  in_weight_sqrt_long_kernel<<<(int)rk::ceil_div(n_rows, 4), 256, 0, st>>>(rowptr, eid, w_coo, n_rows, sq_rows);
+  RK_CHECK_LAUNCH("in_weight_sqrt_long_kernel");
+  return RK_OK;
+}
+
+int launch_sym_scale(const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *w_coo,
+                     const float *sq, int32_t n_rows, int32_t row_offset, float *w_norm, hipStream_t st) {
+  sym_norm_kernel<<<(int)rk::ceil_div(n_rows, 256), 256, 0, st>>>(rowptr, col, eid, w_coo, sq, n_rows, row_offset, w_norm);
+  RK_CHECK_LAUNCH("sym_norm_kernel");
+  sym_norm_long_kernel<<<(int)rk::ceil_div(n_rows, 4), 256, 0, st>>>(rowptr, col, eid, w_coo, sq, n_rows, row_offset,
+                                                                  w_norm);
+  RK_CHECK_LAUNCH("sym_norm_long_kernel");
+  return RK_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rk_in_weight_sqrt_f32(const int32_t *rowptr, const int32_t *eid, const float *w_coo, int32_t n_rows,
+                          float *sqrt_in_w_rows, void *stream) {
+  RK_CHECK_ARG(n_rows >= 0, "negative row count");
+  if (n_rows == 0) return RK_OK;
+  RK_CHECK_ARG(rowptr && eid && w_coo && sqrt_in_w_rows, "null pointer");
+  return launch_in_weight_sqrt(rowptr, eid, w_coo, n_rows, sqrt_in_w_rows, (hipStream_t)stream);
+}
+
+int rk_sym_scale_rows_f32(const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *w_coo,
+                          int32_t n_rows, int32_t row_offset, const float *sqrt_in_w, float *w_norm_coo,
+                          void *stream) {
+  RK_CHECK_ARG(n_rows >= 0 && row_offset >= 0, "negative row count or offset");
+  if (n_rows == 0) return RK_OK;
+  RK_CHECK_ARG(rowptr && col && eid && w_coo && sqrt_in_w && w_norm_coo, "null pointer");
+  return launch_sym_scale(rowptr, col, eid, w_coo, sqrt_in_w, n_rows, row_offset, w_norm_coo, (hipStream_t)stream);
+}
 
 int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
                          const int32_t *eid, const float *w_coo, int32_t n_nodes,
@@ -124,17 +160,9 @@ int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
   RK_CHECK_ARG(n_nodes >= 0, "negative node count");
   if (n_nodes == 0) return RK_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (int)rk::ceil_div(n_nodes, 256);
-  const int wblocks = (int)rk::ceil_div(n_nodes, 4);
-  in_weight_sqrt_kernel<<<blocks, 256, 0, st>>>(rowptr, eid, w_coo, n_nodes, sqrt_in_w);
-  RK_CHECK_LAUNCH("in_weight_sqrt_kernel");
-  in_weight_sqrt_long_kernel<<<wblocks, 256, 0, st>>>(rowptr, eid, w_coo, n_nodes, sqrt_in_w);
-  RK_CHECK_LAUNCH("in_weight_sqrt_long_kernel");
-  sym_norm_kernel<<<blocks, 256, 0, st>>>(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, w_norm_coo);
-  RK_CHECK_LAUNCH("sym_norm_kernel");
-  sym_norm_long_kernel<<<wblocks, 256, 0, st>>>(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, w_norm_coo);
-  RK_CHECK_LAUNCH("sym_norm_long_kernel");
-  return RK_OK;
+  const int rc = launch_in_weight_sqrt(rowptr, eid, w_coo, n_nodes, sqrt_in_w, st);
+  if (rc != RK_OK) return rc;
+  return launch_sym_scale(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, 0, w_norm_coo, st);
 }
 
 int rk_deg_normalize_f32(const int32_t *rowptr, const int32_t *col,

@@ -43,6 +43,29 @@ def all_gather_tensor(t, world, group=None):
     return out
 
 
+def all_gather_rows_into(buf, x_local, group=None):
+    """buf[r * n : (r + 1) * n] = rank r's x_local ([n, D], the same n on every rank); buf is the
+    caller's preallocated [world * n, D] tensor (no list of pieces, no concatenation)."""
+    if _via_host(group) and x_local.is_cuda:
+        host = torch.empty(buf.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host, x_local.detach().cpu().contiguous(), group=group)
+        buf.copy_(host)
+        return buf
+    dist.all_gather_into_tensor(buf, x_local.detach().contiguous(), group=group)
+    return buf
+
+
+def reduce_scatter_rows(out_local, full, group=None):
+    """out_local ([n, D]) = sum over ranks of their full[rank * n : (rank + 1) * n]."""
+    if _via_host(group) and full.is_cuda:
+        host = torch.empty(out_local.shape, dtype=out_local.dtype)
+        dist.reduce_scatter_tensor(host, full.detach().cpu().contiguous(), group=group)
+        out_local.copy_(host)
+        return out_local
+    dist.reduce_scatter_tensor(out_local, full.detach().contiguous(), group=group)
+    return out_local
+
+
 def all_reduce_tensor(t, op=dist.ReduceOp.SUM, group=None):
     if _via_host(group) and t.is_cuda:
         c = t.cpu()
@@ -145,10 +168,10 @@ class ShardedRankingEvaluator:
 # --------------------------------------------------------------------------
 # Row-sharded propagation: rank r owns the destination rows [lo_r, hi_r) of the adjacency and the
 # matching rows of every layer's embeddings.  One hop needs every source row, so it is one
-# all-gather of the layer (N*D*4 bytes in total) followed by the local SpMM; the backward pass is
-# the same step with the transposed operand (rank r owns rows [lo_r, hi_r) of A^T), i.e. one
-# all-gather of the gradient.  Blocks are equal (ceil(N / world), the last one short) so that the
-# gather needs no size exchange.
+# all-gather of the layer (N*D*4 bytes in total) into a buffer that is allocated once, followed by
+# the local SpMM with its fused alpha/beta epilogue; the backward pass is the same step with the
+# transposed operand (rank r owns rows [lo_r, hi_r) of A^T), i.e. one all-gather of the gradient.
+# Blocks are equal (ceil(N / world), the last one short) so that the gather needs no size exchange.
 # --------------------------------------------------------------------------
 def node_range(n_nodes, rank, world):
     block = -(-n_nodes // world)
@@ -156,11 +179,14 @@ def node_range(n_nodes, rank, world):
     return lo, min(lo + block, n_nodes)
 
 
-def _rows_csr(rows, cols, lo, hi):
-    """CSR of the edges whose row falls in [lo, hi), rows re-based to lo, stable in edge order.
-    Returns (rowptr int32 [hi-lo+1], col int32, edge ids int64 into the full list)."""
+def _rows_csr(rows, cols, lo, hi, order_key=None):
+    """CSR of the edges whose row falls in [lo, hi), rows re-based to lo, stable in edge order
+    (order_key: the edges' positions in the full list when `rows` is a subset of it).
+    Returns (rowptr int32 [hi-lo+1], col int32, positions into the given arrays)."""
     rows = np.asarray(rows, np.int64)
     sel = np.nonzero((rows >= lo) & (rows < hi))[0]
+    if order_key is not None:
+        sel = sel[np.argsort(np.asarray(order_key)[sel], kind="stable")]
     order = sel[np.argsort(rows[sel], kind="stable")]
     ptr = np.zeros(hi - lo + 1, np.int64)
     np.cumsum(np.bincount(rows[order] - lo, minlength=hi - lo), out=ptr[1:])
@@ -170,71 +196,129 @@ def _rows_csr(rows, cols, lo, hi):
 class HipRowBlock:
     """The production compute of a row block: recommend_amd.ops SpMM kernels."""
 
-    def __init__(self, rowptr, col, val, device):
+    def __init__(self, rowptr, col, val, device, n_cols=None):
         from . import ops
         self._ops = ops
         eid = np.arange(col.shape[0], dtype=np.int32)
-        self.mat = ops.CsrMatrix(rowptr, col, eid, device)
-        self.mat.set_values_from_coo(torch.from_numpy(np.ascontiguousarray(val, np.float32)).to(device))
+        self.mat = ops.CsrMatrix(rowptr, col, eid, device, n_cols=n_cols)
+        self.set_values(val)
 
-    def matmul(self, h_full):
-        return self._ops.spmm_raw(self.mat, h_full)
+    def set_values(self, val):
+        """Edge values in the block's CSR order (numpy or a tensor on the block's device)."""
+        if not isinstance(val, torch.Tensor):
+            val = torch.from_numpy(np.ascontiguousarray(val, np.float32))
+        self.mat.set_values_from_coo(val.to(self.mat.device, torch.float32))
+
+    def matmul(self, h_full, h0=None, alpha=0.0, beta=1.0):
+        """beta * (A_rows h_full) [+ alpha * h0], the epilogue fused into the SpMM kernel."""
+        return self._ops.spmm_raw(self.mat, h_full, h0, alpha, beta)
 
 
 class _ShardedHop(torch.autograd.Function):
+    """out_local = alpha * h0_local + beta * (A_rows gather(h_local)).  Backward:
+    d h_local = beta * ((A^T)_rows gather(g_local)), d h0_local = alpha * g_local."""
+
     @staticmethod
-    def forward(ctx, h_local, graph):
-        ctx.graph = graph
-        return graph.fwd.matmul(graph.gather_rows(h_local))
+    def forward(ctx, h_local, h0_local, graph, alpha, beta):
+        ctx.graph, ctx.alpha, ctx.beta = graph, alpha, beta
+        ctx.has_h0 = h0_local is not None
+        return graph.fwd.matmul(graph.gather_rows(h_local), h0_local, alpha, beta)
 
     @staticmethod
     def backward(ctx, g_local):
         graph = ctx.graph
-        return graph.bwd.matmul(graph.gather_rows(g_local.contiguous())), None
+        g_local = g_local.contiguous()
+        gh = gh0 = None
+        if ctx.needs_input_grad[0]:
+            gh = graph.bwd.matmul(graph.gather_rows(g_local), None, 0.0, ctx.beta)
+        if ctx.has_h0 and ctx.needs_input_grad[1]:
+            gh0 = g_local * ctx.alpha
+        return gh, gh0, None, None, None
 
 
 class RowShardedGraph:
-    """src/dst/w: the full COO edge list with its (normalised) values, as the reference's
-    GraphConstructor holds it (every rank reads the same list and keeps its rows only).
-    `block_factory(rowptr, col, val, device)` returns an object with `matmul(h_full)`;
-    HipRowBlock in production."""
+    """Rank r's rows of a graph and of its transpose.
+
+    RowShardedGraph(src, dst, w, n_nodes, ...): every rank reads the same full COO edge list (with
+    its normalised values) and keeps its rows only.  RowShardedGraph.from_local_edges(...): the rank
+    hands over only the edges it owns (no rank holds the whole list).
+    `block_factory(rowptr, col, val, device, n_cols=...)` returns an object with
+    `matmul(h_full, h0, alpha, beta)`; HipRowBlock in production."""
 
     def __init__(self, src, dst, w, n_nodes, rank=None, world=None, group=None, device="cuda",
                  block_factory=None):
+        self._init_partition(n_nodes, rank, world, group, device)
+        factory = block_factory or HipRowBlock
+        w = np.asarray(w, np.float32)
+        p, c, e = _rows_csr(dst, src, self.lo, self.hi)       # out[v] = sum over edges u -> v
+        self.fwd = factory(p, c, w[e], device, n_cols=self.n_nodes)
+        p, c, e = _rows_csr(src, dst, self.lo, self.hi)       # rows of the transposed operand
+        self.bwd = factory(p, c, w[e], device, n_cols=self.n_nodes)
+
+    def _init_partition(self, n_nodes, rank, world, group, device):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.n_nodes = int(n_nodes)
         self.block = -(-self.n_nodes // self.world)
         self.lo, self.hi = node_range(self.n_nodes, self.rank, self.world)
+        self.device = torch.device(device)
+        self._gather_buf = {}
+
+    @classmethod
+    def from_local_edges(cls, fwd_rows, bwd_rows, n_nodes, rank=None, world=None, group=None, device="cuda",
+                         block_factory=None):
+        """fwd_rows = (rowptr, col, val) of this rank's destination rows (columns = global source
+        ids), bwd_rows = the same for its rows of the transpose (rows = sources it owns, columns =
+        global destination ids)."""
+        g = cls.__new__(cls)
+        g._init_partition(n_nodes, rank, world, group, device)
         factory = block_factory or HipRowBlock
-        w = np.asarray(w, np.float32)
-        p, c, e = _rows_csr(dst, src, self.lo, self.hi)       # out[v] = sum over edges u -> v
-        self.fwd = factory(p, c, w[e], device)
-        p, c, e = _rows_csr(src, dst, self.lo, self.hi)       # rows of the transposed operand
-        self.bwd = factory(p, c, w[e], device)
+        g.fwd = factory(*fwd_rows, device, n_cols=g.n_nodes)
+        g.bwd = factory(*bwd_rows, device, n_cols=g.n_nodes)
+        return g
 
     def local_rows(self, x_full):
         return x_full[self.lo:self.hi]
 
     def gather_rows(self, x_local):
-        """[hi-lo, D] on every rank -> the full [N, D] matrix on every rank."""
+        """[hi-lo, D] on every rank -> [world * block, D] on every rank: rows [0, N) are the full
+        matrix, the rows behind them padding of the last rank's short block.  The result lives in
+        a buffer that the next gather of the same width overwrites."""
         if self.world == 1:
             return x_local
         n_loc, D = x_local.shape
-        if n_loc < self.block:
-            pad = torch.zeros((self.block - n_loc, D), dtype=x_local.dtype, device=x_local.device)
-            x_local = torch.cat([x_local, pad])
-        parts = all_gather_tensor(x_local.contiguous(), self.world, self.group)
-        return torch.cat(parts)[: self.n_nodes]
+        key = (D, x_local.dtype, x_local.device)
+        bufs = self._gather_buf.get(key)
+        if bufs is None:
+            bufs = (torch.zeros((self.world * self.block, D), dtype=x_local.dtype, device=x_local.device),
+                    torch.zeros((self.block, D), dtype=x_local.dtype, device=x_local.device))
+            self._gather_buf[key] = bufs
+        full, send = bufs
+        if n_loc < self.block:        # the last rank's block is short: send it padded (the pad stays zero)
+            send[:n_loc].copy_(x_local.detach())
+            x_local = send
+        return all_gather_rows_into(full, x_local, self.group)
 
-    def hop(self, h_local):
-        """One hop h <- A h on this rank's rows (differentiable)."""
-        return _ShardedHop.apply(h_local, self)
+    def hop(self, h_local, h0_local=None, alpha=0.0, beta=1.0):
+        """One hop on this rank's rows, h <- alpha*h0 + beta*(A h) (differentiable)."""
+        return _ShardedHop.apply(h_local, h0_local, self, float(alpha), float(beta))
 
     def aggrate(self, x_local, k, alpha):
         """k hops of h <- alpha*h0 + (1-alpha)*A h (graph_constructor.py:189-197), rows sharded."""
         h = x_local
         for _ in range(k):
-            h = alpha * x_local + (1.0 - alpha) * self.hop(h)
+            h = self.hop(h, x_local, alpha, 1.0 - alpha)
+        return h
+
+    def agg_func(self, x_local, k, f, dropout, active, layer=None):
+        """k hops of h <- A dropout(active(f(h))) (graph_constructor.py:199-208) on this rank's rows:
+        the node-wise layer is local, the hop gathers.  `layer(f, h, active, dropout)`: the fused
+        layer (recommend_amd.fused.linear_act unless given)."""
+        if layer is None:
+            from . import fused
+            layer = fused.linear_act
+        h = x_local
+        for _ in range(k):
+            h = self.hop(layer(f, h, active, dropout))
         return h

@@ -202,6 +202,30 @@ def sym_normalize(mat, w_coo):
     return sq, out
 
 
+def in_weight_sqrt(mat, w_local):
+    """sqrt(max(sum of each row's incoming weights, 1e-12)) for the rows of `mat`
+    (graph_constructor.py:177-178); w_local is indexed by mat.eid."""
+    _need_cuda(w_local)
+    w_local = _f32c(w_local)
+    sq = torch.empty(max(mat.n_rows, 1), dtype=torch.float32, device=w_local.device)
+    _ffi.call("rk_in_weight_sqrt_f32", ptr(mat.rowptr), ptr(mat.eid), ptr(w_local), c_int32(mat.n_rows), ptr(sq),
+              stream_ptr(w_local.device))
+    return sq[: mat.n_rows]
+
+
+def sym_scale_rows(mat, w_local, row_offset, sqrt_in_w):
+    """w / (sqrt_in_w[col] * sqrt_in_w[row_offset + row]) for the edges of `mat`
+    (graph_constructor.py:186); sqrt_in_w covers all nodes."""
+    _need_cuda(w_local, sqrt_in_w)
+    w_local, sqrt_in_w = _f32c(w_local), _f32c(sqrt_in_w)
+    if sqrt_in_w.numel() < max(mat.n_cols, row_offset + mat.n_rows):
+        raise ValueError("sqrt_in_w is shorter than the node range the block refers to")
+    out = torch.empty_like(w_local)
+    _ffi.call("rk_sym_scale_rows_f32", ptr(mat.rowptr), ptr(mat.idx), ptr(mat.eid), ptr(w_local), c_int32(mat.n_rows),
+              c_int32(int(row_offset)), ptr(sqrt_in_w), ptr(out), stream_ptr(w_local.device))
+    return out
+
+
 def deg_normalize(mat):
     """w_e = deg_in[src]^-0.5 * deg_in[dst]^-0.5 in COO order."""
     out = torch.empty(mat.nnz, dtype=torch.float32, device=mat.device)

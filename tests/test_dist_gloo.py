@@ -119,15 +119,17 @@ def test_item_sharded_eval_world2_equals_unsharded():
 class OracleRowBlock:
     """matmul(h_full) of one row block in float64 scipy (test-only stand-in for HipRowBlock)."""
 
-    def __init__(self, rowptr, col, val, device):
+    def __init__(self, rowptr, col, val, device, n_cols=None):
         import scipy.sparse as sp
-        n_cols = int(col.max()) + 1 if col.size else 1
-        self.n_cols = n_cols
-        self.m = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(rowptr.shape[0] - 1, n_cols))
+        self.n_cols = n_cols if n_cols is not None else (int(col.max()) + 1 if col.size else 1)
+        self.m = sp.csr_matrix((np.asarray(val, np.float64), col, rowptr), shape=(rowptr.shape[0] - 1, self.n_cols))
 
-    def matmul(self, h_full):
+    def matmul(self, h_full, h0=None, alpha=0.0, beta=1.0):
         h = h_full.detach().numpy().astype(np.float64)[: self.n_cols]
-        return torch.from_numpy((self.m @ h).astype(np.float32))
+        out = beta * (self.m @ h)
+        if h0 is not None:
+            out = out + alpha * h0.detach().numpy().astype(np.float64)
+        return torch.from_numpy(out.astype(np.float32))
 
 
 def _prop_case():

@@ -75,3 +75,124 @@ def test_row_sharded_propagation_on_the_hip_kernels():
     for _rank, lo, hi, out, grad in results:
         assert np.abs(out - h[lo:hi]).max() <= 1e-5 * np.abs(h).max()
         assert np.abs(grad - gx[lo:hi]).max() <= 1e-5 * np.abs(gx).max()
+
+
+# ---------------------------------------------------------------- sharded training step
+class _Cfg:
+    class data:
+        num_users, num_items = 1203, 811
+
+    class model:
+        model_name = "MMFCN"
+        modal_num, emb_dim, layer_num, dropout = 2, 64, 2, 0.0
+
+    class graph:
+        weight_feature = [None]
+        edge_weight_type, add_self_loops, normalize_adj = "uniform", True, True
+
+    class system:
+        device = "cuda:0"
+
+
+def _train_case():
+    rng = np.random.default_rng(21)
+    U, I = _Cfg.data.num_users, _Cfg.data.num_items
+    pairs = np.unique(np.stack([rng.integers(0, U, 9000), rng.integers(0, I, 9000)], 1), axis=0)
+    pairs[:700, 1] = 3                                    # one item row long enough for the chunked-row path
+    pairs = np.unique(pairs, axis=0)
+    pairs = pairs[rng.permutation(len(pairs))]
+    ratings = rng.integers(1, 6, len(pairs)).astype(np.float32)
+    feats = {"image": torch.from_numpy(rng.standard_normal((I, 256)).astype(np.float32)),
+             "text": torch.from_numpy(rng.standard_normal((I, 96)).astype(np.float32))}
+    sel = rng.choice(len(pairs), 257, replace=False)      # odd batch: the ranks' shares differ
+    batch = {"user_ids": torch.from_numpy(pairs[sel, 0]), "item_ids": torch.from_numpy(pairs[sel, 1]),
+             "neg_items": torch.from_numpy(rng.integers(0, I, (257, 1)))}
+    return pairs[:, 0], pairs[:, 1], ratings, feats, batch
+
+
+def _single_process_step():
+    from recommend_amd.loss import gather_dot_bpr_loss
+    from recommend_amd.model import ModelFactory
+    users, items, ratings, feats, batch = _train_case()
+    torch.manual_seed(4)
+    model = ModelFactory.create_Model(_Cfg, {}, feats).to("cuda:0")
+    model.build_graph((users, items, ratings))
+    model.creat_feature_weight()
+    model.train()
+    return model, {k: v.to("cuda:0") for k, v in batch.items()}, gather_dot_bpr_loss
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
+        full, batch, loss_fn = _single_process_step()      # only its parameters are used here
+        users, items, ratings, feats, _ = _train_case()
+        model = ShardedTESTModel(_Cfg, {}, feats).to("cuda:0")
+        model.load_replicated_state(full)
+        U = _Cfg.data.num_users
+        mine = (((users >= model.lo) & (users < model.hi)) | ((items + U >= model.lo) & (items + U < model.hi)))
+        idx = np.flatnonzero(mine)
+        model.build_graph((users[idx], items[idx], ratings[idx]), index=idx, n_total=len(users))
+        model.creat_feature_weight()
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        step = ShardedTrainStep(model, opt, loss_fn, max_grad_norm=1.0)
+        loss = step(batch)
+        torch.cuda.synchronize()
+        grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy()) for k, p in model.named_parameters()}
+        params = {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}
+        q.put((rank, float(loss), float(step.last_grad_norm), grads, params))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_on_the_hip_kernels_equals_single_process():
+    """Two ranks (rows of the graph and of every node matrix sharded, batch split) against the
+    single-process step on the same kernels: loss, clipping norm, every gradient, the parameters
+    after one Adam step.  Dropout is off (the ranks' masks are drawn per local row)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, batch, loss_fn = _single_process_step()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss = loss_fn(model(batch), batch)
+    loss.backward()
+    with_grad = [p for p in model.parameters() if p.grad is not None]
+    want_grads = {k: (None if p.grad is None else p.grad.detach().cpu().numpy().copy())
+                  for k, p in model.named_parameters()}
+    norm = float(torch.nn.utils.clip_grad_norm_(with_grad, 1.0))
+    scale_clip = min(1.0, 1.0 / (norm + 1e-6))
+    opt.step()
+    want = float(loss)
+    for rank, got_loss, gnorm, grads, params in results:
+        assert abs(got_loss - want) <= 1e-5 * abs(want), (rank, got_loss, want)
+        assert abs(gnorm - norm) <= 1e-4 * norm
+        checked = 0
+        for name, p in model.named_parameters():
+            ref = want_grads[name]
+            if ref is None:
+                assert grads[name] is None, name
+                continue
+            ref = ref * scale_clip
+            tol = 2e-5 * float(np.abs(ref).max()) + 1e-12
+            assert float(np.abs(grads[name] - ref).max()) <= tol, (rank, name)
+            new = p.detach().cpu().numpy()
+            assert float(np.abs(params[name] - new).max()) <= 1e-5 * float(np.abs(new).max()) + 5e-6, (rank, name)
+            checked += 1
+        assert checked >= 20
+    for name in results[0][4]:
+        assert np.array_equal(results[0][4][name], results[1][4][name]), name
