@@ -137,8 +137,9 @@ typedef struct rk_spmm_plan {
  * graph_constructor.py:194,205 (also model/sgrec/gcn.py:84, model/mig/mgdcf.py:152):
  *   out[v,:] = sum_{p in row v} val[p] * h[col[p],:]
  * and, when h0 != NULL, the fused epilogue of aggrate (graph_constructor.py:195)
- * and MGDCF (mgdcf.py:152-153):  out = alpha*h0 + beta*(A h).
- * The backward pass is the same call on the CSC arrays (d h = A^T d out).
+ * and MGDCF (mgdcf.py:152-153):  out = alpha*h0 + beta*(A h); with h0 == NULL the result
+ * is beta*(A h) (alpha unused).
+ * The backward pass is the same call on the CSC arrays (d h = beta * A^T d out).
  * plan may be NULL (every row handled by one lane group).  D % 4 == 0. */
 int rk_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                     int32_t n_rows, const float *h, int32_t D, float *out,

@@ -92,15 +92,23 @@ __device__ __forceinline__ void accumulate_edges(const int32_t *__restrict__ col
   }
 }
 
-template <int LPR, bool AXPBY>
+// epilogue of a finished row: kEpiNone out = A h; kEpiAxpby out = alpha*h0 + beta*(A h);
+// kEpiScale out = beta*(A h) (the gradient of the axpby form with respect to h)
+constexpr int kEpiNone = 0, kEpiAxpby = 1, kEpiScale = 2;
+template <int LPR, int AXPBY>
 __device__ __forceinline__ void store_row(float4 *__restrict__ out4, const float4 *__restrict__ h04,
                                           int64_t row, int sub, float4 acc, float alpha, float beta) {
-  if (AXPBY) {
+  if (AXPBY == kEpiAxpby) {
     const float4 z = h04[row * LPR + sub];
     acc.x = alpha * z.x + beta * acc.x;
     acc.y = alpha * z.y + beta * acc.y;
     acc.z = alpha * z.z + beta * acc.z;
     acc.w = alpha * z.w + beta * acc.w;
+  } else if (AXPBY == kEpiScale) {
+    acc.x *= beta;
+    acc.y *= beta;
+    acc.z *= beta;
+    acc.w *= beta;
   }
   out4[row * LPR + sub] = acc;
 }
@@ -113,7 +121,7 @@ struct PlanArgs {
   float4 *partial4;
 };
 
-template <int LPR, bool AXPBY>
+template <int LPR, int AXPBY>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ val, int32_t n_rows, const float4 *__restrict__ h4,
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
 }
 
 // one wavefront per row that was cut into several chunks
-template <int LPR, bool AXPBY>
+template <int LPR, int AXPBY>
 __global__ __launch_bounds__(256) void spmm_multi_reduce_kernel(
     const int32_t *__restrict__ multi_rows, const int32_t *__restrict__ multi_slot_ptr,
     int32_t n_multi, const float4 *__restrict__ partial4, float4 *__restrict__ out4,
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void spmm_multi_reduce_kernel(
   if (g == 0) store_row<LPR, AXPBY>(out4, h04, multi_rows[i], sub, acc, alpha, beta);
 }
 
-template <int LPR, bool AXPBY>
+template <int LPR, int AXPBY>
 int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *val, int32_t n_rows,
                 const float *h, float *out, const float *h0, float alpha, float beta,
                 const rk_spmm_plan *plan, hipStream_t st) {
@@ -213,8 +221,9 @@ template <int LPR>
 int dispatch_axpby(const int32_t *rowptr, const int32_t *col, const float *val, int32_t n_rows,
                    const float *h, float *out, const float *h0, float alpha, float beta,
                    const rk_spmm_plan *plan, hipStream_t st) {
-  return h0 ? launch_spmm<LPR, true>(rowptr, col, val, n_rows, h, out, h0, alpha, beta, plan, st)
-            : launch_spmm<LPR, false>(rowptr, col, val, n_rows, h, out, h0, alpha, beta, plan, st);
+  if (h0) return launch_spmm<LPR, kEpiAxpby>(rowptr, col, val, n_rows, h, out, h0, alpha, beta, plan, st);
+  if (beta != 1.0f) return launch_spmm<LPR, kEpiScale>(rowptr, col, val, n_rows, h, out, h0, alpha, beta, plan, st);
+  return launch_spmm<LPR, kEpiNone>(rowptr, col, val, n_rows, h, out, h0, alpha, beta, plan, st);
 }
 
 }  // namespace

@@ -139,7 +139,7 @@ class CsrMatrix:
 
 
 def spmm_raw(mat, h, h0=None, alpha=0.0, beta=1.0, out=None):
-    """out = A h  (h0 is None)  or  alpha*h0 + beta*(A h); no autograd."""
+    """out = beta*(A h)  (h0 is None)  or  alpha*h0 + beta*(A h); no autograd."""
     _need_cuda(h, h0)
     if mat.val is None:
         raise ValueError("sparse matrix has no edge values yet")
@@ -179,9 +179,7 @@ class _SpMM(torch.autograd.Function):
         g = _f32c(g)
         gh = gh0 = None
         if ctx.needs_input_grad[0]:
-            gh = spmm_raw(ctx.bwd_mat, g)
-            if ctx.has_h0 and ctx.beta != 1.0:
-                gh = gh * ctx.beta
+            gh = spmm_raw(ctx.bwd_mat, g, None, 0.0, ctx.beta)
         if ctx.has_h0 and ctx.needs_input_grad[1]:
             gh0 = g * ctx.alpha
         return gh, gh0, None, None, None, None

@@ -191,7 +191,8 @@ def test_sharded_training_step_on_the_hip_kernels_equals_single_process():
             tol = 2e-5 * float(np.abs(ref).max()) + 1e-12
             assert float(np.abs(grads[name] - ref).max()) <= tol, (rank, name)
             new = p.detach().cpu().numpy()
-            assert float(np.abs(params[name] - new).max()) <= 1e-5 * float(np.abs(new).max()) + 5e-6, (rank, name)
+            # (Adam divides by |g| + 1e-8: gradient elements of that size turn rounding into a few percent of lr)
+            assert float(np.abs(params[name] - new).max()) <= 1e-5 * float(np.abs(new).max()) + 2e-5, (rank, name)
             checked += 1
         assert checked >= 20
     for name in results[0][4]:
