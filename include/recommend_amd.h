@@ -162,7 +162,7 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
                     int32_t D, int32_t n_users, float *dW, float *db, void *ws,
                     size_t ws_bytes, void *stream);
 
-/* ---- W2: node-wise 64 -> 64 layers around the hops (device; fp32 results) ---- */
+/* ---- W2: node-wise D -> D layers around the hops, D = 64 or 128 (device; fp32 results) ---- */
 /* Replaces dropout(active(f(h))) with f = Linear, active = PReLU (one slope) in
  * agg_func (graph_constructor.py:204), Combine (Combin_Layer.py:26-30: the sum of
  * two Linears is the X2/W2 pair), MGCN's embedding branch (out_Layer.py:36: R is
@@ -176,8 +176,9 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
  * a step counter mixed into the seed when the kernel runs, so that a launch
  * replayed from a captured HIP graph draws a new mask every step; forward and
  * backward of one layer must see the same seed and the same counter value.
- * W: D x K (nn.Linear layout).  Built for K = D = 64.
- * Arithmetic: every fp32 operand is split into three bf16 parts and the six
+ * W: D x K (nn.Linear layout).  Built for K = D = 64 and K = D = 128.
+ * Arithmetic at D = 128: fp32-input MFMA, an fp32 fma chain per output element.
+ * Arithmetic at D = 64: every fp32 operand is split into three bf16 parts and the six
  * leading partial products are summed in fp32 on the bf16 matrix pipe: the error
  * of a product is that of an fp32 dot product (<= 1e-6 of sum |x_k w_k|); operands
  * beyond bf16's largest finite value (3.39e38) yield NaN. */

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "dense_wide.h"
 #include "slab_reduce.h"
 
 namespace {
@@ -750,8 +751,8 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                      uint64_t seed, const uint64_t *seed_step, const float *residual, int64_t n_rows,
                      int32_t K, int32_t D, float *Y, void *stream) {
   RK_CHECK_ARG(n_rows >= 0, "negative row count");
-  if (K != DD || D != DD)
-    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_fwd_f32: only 64 -> 64 layers are built (got %d -> %d)", K, D);
+  if (K != D || (D != DD && D != 128))
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_fwd_f32: built for 64 -> 64 and 128 -> 128 layers (got %d -> %d)", K, D);
   if (n_rows == 0) return RK_OK;
   RK_CHECK_ARG(X1 && W1 && Y, "null pointer");
   RK_CHECK_ARG((X2 == nullptr) == (W2 == nullptr), "X2 and W2 go together");
@@ -760,6 +761,8 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
                    rk::aligned16(Y),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    return rk::dense128_fwd(X1, W1, X2, W2, b1, b2, alpha, p_drop, seed, seed_step, residual, n_rows, Y, st);
   // the plain layer fits two workgroups per CU (256 registers, 64 KB of LDS): a second wavefront per
   // SIMD splits operands and runs the epilogue while the first one multiplies (32.6 -> 29.9 us at
   // 255k rows); the two-input and the residual variants need the whole CU
@@ -782,6 +785,7 @@ int rk_dense_fwd_f32(const float *X1, const float *W1, const float *X2, const fl
 }
 
 size_t rk_dense_bwd_ws_bytes(int64_t n_rows, int32_t K, int32_t D) {
+  if (n_rows > 0 && K == 128 && D == 128) return rk::dense128_bwd_ws_bytes();
   if (n_rows <= 0 || K != DD || D != DD) return 0;
   // sized for the largest grid, so that the answer does not depend on the device queried
   return ((size_t)kBwdMaxGrid * PART + (size_t)rk::kSlabMaxSeg * NRED) * sizeof(float);
@@ -792,14 +796,16 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                      int32_t D, float *dX,
                      float *dW, float *db, float *dalpha, void *ws, size_t ws_bytes, void *stream) {
   RK_CHECK_ARG(n_rows > 0, "empty layer input");
-  if (K != DD || D != DD)
-    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_f32: only 64 -> 64 layers are built (got %d -> %d)", K, D);
+  if (K != D || (D != DD && D != 128))
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_f32: built for 64 -> 64 and 128 -> 128 layers (got %d -> %d)", K, D);
   RK_CHECK_ARG(X && W && G && dW && ws, "null pointer");
   RK_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "dropout probability must be in [0, 1)");
   RK_CHECK_ARG(ws_bytes >= rk_dense_bwd_ws_bytes(n_rows, K, D), "workspace too small");
   RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(G) && rk::aligned16(dX),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    return rk::dense128_bwd(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, dW, db, dalpha, ws, st);
   const int grid = bwd_grid(n_rows);
   if (alpha)
     dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);

@@ -369,7 +369,7 @@ def set_dropout_step_tensor(t):
     _dropout_step[t.device] = t
 
 
-DENSE_WIDTHS = (64,)   # K = D of the built rk_dense_* kernels
+DENSE_WIDTHS = (64, 128)   # K = D of the built rk_dense_* kernels
 
 
 def dense_supported(x, weight):
@@ -439,7 +439,7 @@ class _Dense(torch.autograd.Function):
 def dense(x, weight, bias=None, alpha=None, p=0.0, residual=None, x2=None, weight2=None, bias2=None,
           seed=None):
     """Y = dropout(prelu(x W^T [+ x2 W2^T] + b [+ b2], alpha), p) [+ residual] in one kernel
-    (64 -> 64 layers).  alpha None: no activation; p == 0: no dropout."""
+    (64 -> 64 and 128 -> 128 layers).  alpha None: no activation; p == 0: no dropout."""
     p = float(p)
     if seed is None:
         seed = next_dropout_seed() if p > 0.0 else 0

@@ -17,20 +17,21 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def make(n, seed):
+def make(n, seed, D=64):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, 64, generator=g)
-    w = torch.randn(64, 64, generator=g) / 8
-    b = torch.randn(64, generator=g)
-    r = torch.randn(n, 64, generator=g)
-    go = torch.randn(n, 64, generator=g)
+    x = torch.randn(n, D, generator=g)
+    w = torch.randn(D, D, generator=g) / 8
+    b = torch.randn(D, generator=g)
+    r = torch.randn(n, D, generator=g)
+    go = torch.randn(n, D, generator=g)
     return x, w, b, r, go
 
 
+@pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("n", [1, 63, 64, 130, 1000, 70000])
 @pytest.mark.parametrize("act,res", [(True, False), (True, True), (False, False)])
-def test_dense_forward_backward_no_dropout(n, act, res):
-    x, w, b, r, go = make(n, n)
+def test_dense_forward_backward_no_dropout(n, act, res, D):
+    x, w, b, r, go = make(n, n, D)
     alpha = torch.tensor([0.25])
     xd = x.to(DEV).requires_grad_(True)
     wd = w.to(DEV).requires_grad_(True)
@@ -58,10 +59,11 @@ def test_dense_forward_backward_no_dropout(n, act, res):
         assert torch.equal(rd.grad.cpu(), go)
 
 
-def test_dense_two_input_linear_sum():
+@pytest.mark.parametrize("D", [64, 128])
+def test_dense_two_input_linear_sum(D):
     n = 5000
-    x1, w1, b1, _, go = make(n, 1)
-    x2, w2, b2, _, _ = make(n, 2)
+    x1, w1, b1, _, go = make(n, 1, D)
+    x2, w2, b2, _, _ = make(n, 2, D)
     t = [v.to(DEV).requires_grad_(True) for v in (x1, w1, b1, x2, w2, b2)]
     y = ops.dense(t[0], t[1], t[2], x2=t[3], weight2=t[4], bias2=t[5])
     y.backward(go.to(DEV))
@@ -73,12 +75,13 @@ def test_dense_two_input_linear_sum():
         assert rel(a.grad, b.grad) <= 1e-5
 
 
+@pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("act", [True, False])
-def test_dense_dropout_is_consistent_and_unbiased(act):
+def test_dense_dropout_is_consistent_and_unbiased(act, D):
     """Dropout uses its own counter hash: check the keep rate, the 1/(1-p) scaling,
     that forward and backward use the same mask, and seed reproducibility."""
     n, p = 20000, 0.3
-    x, w, b, _, go = make(n, 7)
+    x, w, b, _, go = make(n, 7, D)
     alpha = torch.tensor([0.25], device=DEV, requires_grad=True) if act else None
     xd = x.to(DEV).requires_grad_(True)
     wd = w.to(DEV).requires_grad_(True)
