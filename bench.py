@@ -34,6 +34,7 @@ from recommend_amd.evaluator import RankingEvaluator  # noqa: E402
 from recommend_amd.graph_constructor import GraphConstructor  # noqa: E402
 from recommend_amd.loss import gather_dot_bpr_loss  # noqa: E402
 from recommend_amd.model import ModelFactory  # noqa: E402
+from recommend_amd.optim import FusedClipAdam  # noqa: E402
 from recommend_amd.sampler import NegativeSampler, TrainBatchLoader, build_user_csr  # noqa: E402
 from recommend_amd.train_step import GraphedTrainStep  # noqa: E402
 
@@ -273,7 +274,7 @@ def main():
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
         dp, di = sampler.device_csr(dev)
         loader = TrainBatchLoader(tu, ti, tr, BATCH[args.shape], sampler, device=dev, resolve_on_host=False)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
+        opt = FusedClipAdam(model.parameters(), lr=1e-3)
         model.train()
         n_steps = len(loader) if args.epoch_steps < 0 else min(args.epoch_steps, len(loader))
         it = iter(loader)

@@ -198,6 +198,17 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b,
                      int32_t K, int32_t D, float *dX, float *dW, float *db,
                      float *dalpha, void *ws, size_t ws_bytes, void *stream);
 
+/* The same with `accumulate`: if non-zero, dW, db and dalpha are ADDED to what the outputs hold
+ * (the same Linear applied k times in agg_func, graph_constructor.py:203-205: one gradient buffer
+ * for all k applications); dX is always overwritten. */
+int rk_dense_bwd_accum_f32(const float *X, const float *W, const float *b,
+                           const float *alpha, float p_drop, uint64_t seed,
+                           const uint64_t *seed_step, const float *G,
+                           int64_t n_rows, int32_t K, int32_t D, float *dX,
+                           float *dW, float *db, float *dalpha,
+                           int32_t accumulate, void *ws, size_t ws_bytes,
+                           void *stream);
+
 /* ---- W2: modality-weighted sum (device) ---------------------------------- */
 /* Replaces torch.sum(torch.stack(modal_features) * softmax(alphas)[:, None, None], 0),
  * model/test/out_Layer.py:52-54, and its autograd: out = sum_m softmax(alphas)_m F_m
@@ -212,6 +223,31 @@ int rk_modal_sum_bwd_f32(const float *const *F_host, float *const *dF_host,
                          int32_t M, const float *alphas, const float *G,
                          int64_t n_elem, float *dalpha, void *ws, size_t ws_bytes,
                          void *stream);
+
+/* ---- optimizer half of the training step (device) ------------------------- */
+/* Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
+ * torch.optim.Adam.step(), train/graph_trainer.py:151-156, for a list of fp32 tensors in two
+ * launches (two per 48 tensors).  tensors_host: HOST array of descriptors (device pointers
+ * inside); they travel to the kernels in the launch arguments, so the call neither copies nor
+ * allocates and can be recorded in a HIP graph.  ws: rk_adam_ws_bytes() bytes of scratch.
+ * step: device counter, incremented by the call (bias correction uses the new value); lr: device
+ * scalar.  max_norm <= 0: no clipping.  norm_out (may be NULL): the gradients' total 2-norm
+ * before clipping.  Update rule and clip factor as torch computes them:
+ *   coef = min(1, max_norm / (norm + 1e-6));  g = coef * grad + weight_decay * p
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2
+ *   p = p - lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)                   */
+typedef struct rk_adam_tensor {
+  float *param;
+  const float *grad;
+  float *exp_avg;
+  float *exp_avg_sq;
+  int64_t n;
+} rk_adam_tensor;
+size_t rk_adam_ws_bytes(const rk_adam_tensor *tensors_host, int32_t n_tensors);
+int rk_adam_clip_step_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors,
+                          int64_t *step, const float *lr, float beta1, float beta2,
+                          float eps, float weight_decay, float max_norm,
+                          float *norm_out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
 /* Replaces GraphDataLoader._generate_negative_samples,

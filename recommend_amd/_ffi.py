@@ -29,6 +29,11 @@ class RkError(RuntimeError):
         self.message = message
 
 
+class AdamTensor(Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("n", c_int64)]
+
+
 class SpmmPlan(Structure):
     _fields_ = [
         ("long_thresh", c_int32),
@@ -70,9 +75,14 @@ SIGNATURES = {
     "rk_dense_bwd_ws_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "rk_dense_bwd_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
                                    P, P, P, P, P, c_size_t, P]),
+    "rk_dense_bwd_accum_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
+                                         P, P, P, P, c_int32, P, c_size_t, P]),
     "rk_modal_sum_fwd_f32": (c_int32, [P, c_int32, P, c_int64, P, P]),
     "rk_modal_sum_bwd_ws_bytes": (c_size_t, []),
     "rk_modal_sum_bwd_f32": (c_int32, [P, P, c_int32, P, P, c_int64, P, P, c_size_t, P]),
+    "rk_adam_ws_bytes": (c_size_t, [P, c_int32]),
+    "rk_adam_clip_step_f32": (c_int32, [P, c_int32, P, P, c_float, c_float, c_float, c_float, c_float, P, P,
+                                        c_size_t, P]),
     "rk_mt_seed_host": (c_int32, [P, c_uint64]),
     "rk_neg_sample_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P]),
     "rk_bpr_ws_bytes": (c_size_t, [c_int64, c_int32]),

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, 1) void dense_bwd_kernel(
 constexpr int NRED = DD * DD + DD + 1;
 __global__ __launch_bounds__(256) void dense_reduce_kernel(const float *__restrict__ slab, int32_t n_part,
                                                            float *__restrict__ dW, float *__restrict__ db,
-                                                           float *__restrict__ dalpha) {
+                                                           float *__restrict__ dalpha, int accumulate) {
   __shared__ float red[16][17];
   const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + el;
@@ -712,12 +712,13 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float *__restri
   float s = 0.0f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += red[k][el];
+  // accumulate: the sums are added to what the outputs hold (a weight shared by several layers)
   if (i < DD * DD)
-    dW[i] = s;
+    dW[i] = accumulate ? dW[i] + s : s;
   else if (i < DD * DD + DD) {
-    if (db) db[i - DD * DD] = s;
+    if (db) db[i - DD * DD] = accumulate ? db[i - DD * DD] + s : s;
   } else if (dalpha)
-    dalpha[0] = s;
+    dalpha[0] = accumulate ? dalpha[0] + s : s;
 }
 
 inline int cu_count() {
@@ -795,6 +796,14 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                      uint64_t seed, const uint64_t *seed_step, const float *G, int64_t n_rows, int32_t K,
                      int32_t D, float *dX,
                      float *dW, float *db, float *dalpha, void *ws, size_t ws_bytes, void *stream) {
+  return rk_dense_bwd_accum_f32(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, K, D, dX, dW, db, dalpha, 0, ws,
+                                ws_bytes, stream);
+}
+
+int rk_dense_bwd_accum_f32(const float *X, const float *W, const float *b, const float *alpha, float p_drop,
+                           uint64_t seed, const uint64_t *seed_step, const float *G, int64_t n_rows, int32_t K,
+                           int32_t D, float *dX, float *dW, float *db, float *dalpha, int32_t accumulate, void *ws,
+                           size_t ws_bytes, void *stream) {
   RK_CHECK_ARG(n_rows > 0, "empty layer input");
   if (K != D || (D != DD && D != 128))
     return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_f32: built for 64 -> 64 and 128 -> 128 layers (got %d -> %d)", K, D);
@@ -805,14 +814,14 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (D == 128)
-    return rk::dense128_bwd(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, dW, db, dalpha, ws, st);
+    return rk::dense128_bwd(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, dW, db, dalpha, accumulate, ws, st);
   const int grid = bwd_grid(n_rows);
   if (alpha)
     dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
   else
     dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
   RK_CHECK_LAUNCH("dense_bwd_kernel");
-  dense_reduce_kernel<<<(NRED + 15) / 16, 256, 0, st>>>((const float *)ws, grid, dW, db, dalpha);
+  dense_reduce_kernel<<<(NRED + 15) / 16, 256, 0, st>>>((const float *)ws, grid, dW, db, dalpha, accumulate);
   RK_CHECK_LAUNCH("dense_reduce_kernel");
   return RK_OK;
 }

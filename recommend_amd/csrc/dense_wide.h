@@ -11,6 +11,6 @@ int dense128_fwd(const float *X1, const float *W1, const float *X2, const float 
 size_t dense128_bwd_ws_bytes();
 int dense128_bwd(const float *X, const float *W, const float *b, const float *alpha, float p_drop, uint64_t seed,
                  const uint64_t *seed_step, const float *G, int64_t n_rows, float *dX, float *dW, float *db,
-                 float *dalpha, void *ws, hipStream_t st);
+                 float *dalpha, int accumulate, void *ws, hipStream_t st);
 
 }  // namespace rk

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void dense128_bwd_kernel(
 // partials summed in workgroup order, 16 lanes per element (as dense.hip's reduction)
 __global__ __launch_bounds__(256) void dense128_reduce_kernel(const float *__restrict__ slab, int32_t n_part,
                                                               float *__restrict__ dW, float *__restrict__ db,
-                                                              float *__restrict__ dalpha) {
+                                                              float *__restrict__ dalpha, int accumulate) {
   __shared__ float red[16][17];
   const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + el;
@@ -334,11 +334,11 @@ __global__ __launch_bounds__(256) void dense128_reduce_kernel(const float *__res
 #pragma unroll
   for (int k = 0; k < 16; ++k) s += red[k][el];
   if (idx < DW * DW)
-    dW[idx] = s;
+    dW[idx] = accumulate ? dW[idx] + s : s;
   else if (idx < DW * DW + DW) {
-    if (db) db[idx - DW * DW] = s;
+    if (db) db[idx - DW * DW] = accumulate ? db[idx - DW * DW] + s : s;
   } else if (dalpha)
-    dalpha[0] = s;
+    dalpha[0] = accumulate ? dalpha[0] + s : s;
 }
 
 constexpr int kMaxGrid = 512;
@@ -381,7 +381,7 @@ size_t dense128_bwd_ws_bytes() { return (size_t)kMaxGrid * PARTW * sizeof(float)
 
 int dense128_bwd(const float *X, const float *W, const float *b, const float *alpha, float p_drop, uint64_t seed,
                  const uint64_t *seed_step, const float *G, int64_t n_rows, float *dX, float *dW, float *db,
-                 float *dalpha, void *ws, hipStream_t st) {
+                 float *dalpha, int accumulate, void *ws, hipStream_t st) {
   const int grid = grid_for(n_rows);
   if (alpha)
     dense128_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, (float *)ws);
@@ -389,7 +389,7 @@ int dense128_bwd(const float *X, const float *W, const float *b, const float *al
     dense128_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX,
                                                      (float *)ws);
   RK_CHECK_LAUNCH("dense128_bwd_kernel");
-  dense128_reduce_kernel<<<(NREDW + 15) / 16, 256, 0, st>>>((const float *)ws, grid, dW, db, dalpha);
+  dense128_reduce_kernel<<<(NREDW + 15) / 16, 256, 0, st>>>((const float *)ws, grid, dW, db, dalpha, accumulate);
   RK_CHECK_LAUNCH("dense128_reduce_kernel");
   return RK_OK;
 }

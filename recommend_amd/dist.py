@@ -300,6 +300,21 @@ class RowShardedGraph:
             x_local = send
         return all_gather_rows_into(full, x_local, self.group)
 
+    def hops(self):
+        """The propagation on raw tensors for callers that run their own backward pass
+        (recommend_amd.mgcn_op): forward(z) = A_rows gather(z), backward(g) = (A^T)_rows gather(g)."""
+        graph = self
+
+        class _Hops:
+            @staticmethod
+            def forward(z):
+                return graph.fwd.matmul(graph.gather_rows(z))
+
+            @staticmethod
+            def backward(g):
+                return graph.bwd.matmul(graph.gather_rows(g))
+        return _Hops
+
     def hop(self, h_local, h0_local=None, alpha=0.0, beta=1.0):
         """One hop on this rank's rows, h <- alpha*h0 + beta*(A h) (differentiable)."""
         return _ShardedHop.apply(h_local, h0_local, self, float(alpha), float(beta))

@@ -137,6 +137,9 @@ class ShardedGraphConstructor:
     def propagate(self, node_x):
         return self.graph.hop(node_x)
 
+    def hops(self):
+        return self.graph.hops()
+
 
 class _GatherRows(torch.autograd.Function):
     """[hi-lo, D] on every rank -> the full [N, D] matrix on every rank.  Backward: every rank holds

@@ -210,6 +210,12 @@ class GraphConstructor:
             h = ops.spmm(fwd, bwd, h)
         return h
 
+    def hops(self):
+        """The propagation on raw tensors, forward (A z) and backward (A^T g), for callers that run
+        their own backward pass (recommend_amd.mgcn_op)."""
+        from .mgcn_op import SpmmHops
+        return SpmmHops(*self._operands())
+
     def propagate(self, node_x):
         """One hop h <- A h (the primitive every model variant shares)."""
         fwd, bwd = self._operands()

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused, ops
+from . import fused, mgcn_op, ops
 from .graph_constructor import GraphConstructor
 
 
@@ -75,11 +75,9 @@ class MGCN(nn.Module):
         self.active = MyPReLU()
 
     def forward(self, g, X, emb, k):
-        agg_X = self.agg(X, g, k)
-        for f in self.combine:
-            agg_X = f(X, agg_X)
-        # agg_X + dropout(active(W_o(emb))), out_Layer.py:36
-        return fused.linear_act(self.W_o, emb, self.active, self.dropout, residual=agg_X)
+        # agg -> Combine layers -> agg_X + dropout(active(W_o(emb))) (out_Layer.py:32-36) as one
+        # autograd node over the layer and hop kernels
+        return mgcn_op.mgcn_forward(self, g.hops(), X, emb, k)
 
 
 class TEST(nn.Module):

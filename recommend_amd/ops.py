@@ -377,12 +377,57 @@ def dense_supported(x, weight):
             and x.shape[1] == weight.shape[1])
 
 
+def dense_fwd_raw(x1, w1, b1=None, x2=None, w2=None, b2=None, alpha=None, p=0.0, seed=0, residual=None):
+    """Y = dropout(prelu(x1 w1^T [+ x2 w2^T] + b1 [+ b2], alpha), p) [+ residual]; no autograd.
+    Tensors are contiguous fp32 on one HIP device."""
+    _need_cuda(x1, w1, b1, x2, w2, b2, alpha, residual)
+    if x2 is not None and (alpha is not None or p > 0.0):
+        raise ValueError("the two-input form is linear only (no activation / dropout)")
+    if alpha is not None and alpha.numel() != 1:
+        raise ValueError("only a single PReLU slope is supported")
+    n, K = x1.shape
+    D = w1.shape[0]
+    y = torch.empty((n, D), dtype=torch.float32, device=x1.device)
+    step = _dropout_step.get(x1.device) if p > 0.0 else None
+    _ffi.call("rk_dense_fwd_f32", ptr(x1), ptr(w1), ptr(x2), ptr(w2), ptr(b1), ptr(b2), ptr(alpha),
+              c_float(p), _ffi.c_uint64(seed), ptr(step), ptr(residual), c_int64(n), c_int32(K),
+              c_int32(D), ptr(y), stream_ptr(y.device))
+    return y
+
+
+def dense_bwd_ws(n, K, D, device):
+    return torch.empty(_ffi.load().rk_dense_bwd_ws_bytes(n, K, D) // 4 + 4, dtype=torch.float32, device=device)
+
+
+def dense_bwd_raw(x, w, b, alpha, p, seed, g, want_dx=True, want_db=True, grads=None, ws=None):
+    """Backward of the single-input layer for upstream gradient g -> (dX or None, dW, db or None,
+    dalpha or None).  grads = (dW, db, dalpha) buffers to ADD the weight gradients to (a layer
+    applied several times); otherwise fresh tensors are written.  The dropout step counter
+    registered for the device is mixed into the seed exactly as the forward call did."""
+    _need_cuda(x, w, b, alpha, g)
+    n, K = x.shape
+    D = w.shape[0]
+    dev = g.device
+    if ws is None:
+        ws = dense_bwd_ws(n, K, D, dev)
+    dx = torch.empty_like(x) if want_dx else None
+    acc = grads is not None
+    if acc:
+        dw, db, da = grads
+    else:
+        dw = torch.empty_like(w)
+        db = torch.empty(D, dtype=torch.float32, device=dev) if want_db else None
+        da = torch.empty(1, dtype=torch.float32, device=dev) if alpha is not None else None
+    step = _dropout_step.get(dev) if p > 0.0 else None
+    _ffi.call("rk_dense_bwd_accum_f32", ptr(x), ptr(w), ptr(b), ptr(alpha), c_float(p), _ffi.c_uint64(seed),
+              ptr(step), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw), ptr(db), ptr(da),
+              c_int32(1 if acc else 0), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(dev))
+    return dx, dw, db, da
+
+
 class _Dense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, w1, b1, x2, w2, b2, alpha, residual, p, seed):
-        _need_cuda(x1, w1, b1, x2, w2, b2, alpha, residual)
-        if x2 is not None and (alpha is not None or p > 0.0):
-            raise ValueError("the two-input form is linear only (no activation / dropout)")
         x1, w1 = _f32c(x1), _f32c(w1)
         b1 = _f32c(b1) if b1 is not None else None
         if x2 is not None:
@@ -391,16 +436,7 @@ class _Dense(torch.autograd.Function):
         if residual is not None:
             residual = _f32c(residual)
         alpha_c = _f32c(alpha) if alpha is not None else None
-        if alpha_c is not None and alpha_c.numel() != 1:
-            raise ValueError("only a single PReLU slope is supported")
-        n, K = x1.shape
-        D = w1.shape[0]
-        y = torch.empty((n, D), dtype=torch.float32, device=x1.device)
-        step = _dropout_step.get(x1.device) if p > 0.0 else None
-        _ffi.call("rk_dense_fwd_f32", ptr(x1), ptr(w1), ptr(x2), ptr(w2), ptr(b1), ptr(b2), ptr(alpha_c),
-                  c_float(p), _ffi.c_uint64(seed), ptr(step), ptr(residual), c_int64(n), c_int32(K),
-                  c_int32(D), ptr(y), stream_ptr(y.device))
-        ctx.step = step
+        y = dense_fwd_raw(x1, w1, b1, x2, w2, b2, alpha_c, p, seed, residual)
         ctx.save_for_backward(x1, w1, b1, x2, w2, alpha_c)
         ctx.p, ctx.seed = p, seed
         ctx.has = (b1 is not None, b2 is not None, residual is not None)
@@ -412,26 +448,12 @@ class _Dense(torch.autograd.Function):
         has_b1, has_b2, has_res = ctx.has
         g = _f32c(g)
         n, K = x1.shape
-        D = w1.shape[0]
-        dev = g.device
-        lib = _ffi.load()
-        ws = torch.empty(lib.rk_dense_bwd_ws_bytes(n, K, D) // 4 + 4, dtype=torch.float32, device=dev)
-
-        def run(x, w, b, want_dx, al):
-            dx = torch.empty_like(x) if want_dx else None
-            dw = torch.empty_like(w)
-            db = torch.empty(D, dtype=torch.float32, device=dev)
-            da = torch.empty(1, dtype=torch.float32, device=dev) if al is not None else None
-            _ffi.call("rk_dense_bwd_f32", ptr(x), ptr(w), ptr(b), ptr(al), c_float(ctx.p),
-                      _ffi.c_uint64(ctx.seed), ptr(ctx.step), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw),
-                      ptr(db), ptr(da), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(dev))
-            return dx, dw, db, da
-
+        ws = dense_bwd_ws(n, K, w1.shape[0], g.device)
         need = ctx.needs_input_grad
-        dx1, dw1, db, da = run(x1, w1, b1, need[0], alpha)
+        dx1, dw1, db, da = dense_bwd_raw(x1, w1, b1, alpha, ctx.p, ctx.seed, g, need[0], True, None, ws)
         dx2 = dw2 = None
         if x2 is not None:
-            dx2, dw2, _db2, _ = run(x2, w2, None, need[3], None)
+            dx2, dw2, _db2, _ = dense_bwd_raw(x2, w2, None, None, ctx.p, ctx.seed, g, need[3], False, None, ws)
         return (dx1, dw1, db if has_b1 else None, dx2, dw2, db if has_b2 else None,
                 da, g if has_res else None, None, None)
 

@@ -24,13 +24,18 @@ class GraphedTrainStep:
         """example_batch: a batch dict as the loader yields it (device tensors); its tensors fix
         the captured shapes, and the warm-up steps train on it (they are real steps).  constants: entries every batch carries unchanged (e.g. the
         user->positives CSR for in-kernel negative lookup); they are not copied per step.
-        The optimizer must be capturable (e.g. Adam(capturable=True))."""
+        The optimizer must be capturable (recommend_amd.optim.FusedClipAdam, or e.g.
+        torch.optim.Adam(capturable=True))."""
         if warmup_steps < 1:
             # optimizers create their state on the first step; created inside the capture it would
             # be re-zeroed by every replay
             raise ValueError("at least one eager warm-up step is needed before the capture")
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.max_grad_norm = max_grad_norm
+        # an optimizer that clips inside its own update (recommend_amd.optim.FusedClipAdam)
+        self._opt_clips = hasattr(optimizer, "max_grad_norm")
+        if self._opt_clips:
+            optimizer.max_grad_norm = max_grad_norm
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = next(iter(example_batch.values())).device
         self.constants = dict(constants or {})
@@ -55,7 +60,7 @@ class GraphedTrainStep:
         self.step_counter.add_(1)
         loss = self.loss_fn(self.model(batch), batch)
         loss.backward()
-        if self.max_grad_norm is not None:
+        if self.max_grad_norm is not None and not self._opt_clips:
             self._clip()
         self.opt.step()
         return loss.detach()

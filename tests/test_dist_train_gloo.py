@@ -83,17 +83,35 @@ class NumpyNormalizer:
 
 
 def patch_layers():
-    """torch stand-ins for the fused layer kernels (dropout is off in this test)."""
+    """torch stand-ins for the layer kernels (dropout is off in this test)."""
     from recommend_amd import fused, ops
 
-    def linear_act(linear, x, active=None, dropout=None, residual=None):
-        y = linear(x)
-        if active is not None:
-            y = F.prelu(y, fused.prelu_slope(active))
-        return y if residual is None else residual + y
+    def dense_fwd_raw(x1, w1, b1=None, x2=None, w2=None, b2=None, alpha=None, p=0.0, seed=0, residual=None):
+        y = F.linear(x1, w1, b1)
+        if x2 is not None:
+            y = y + F.linear(x2, w2, b2)
+        if alpha is not None:
+            y = F.prelu(y, alpha)
+        return y if residual is None else y + residual
 
+    def dense_bwd_raw(x, w, b, alpha, p, seed, g, want_dx=True, want_db=True, grads=None, ws=None):
+        dz, da = g, None
+        if alpha is not None:
+            z = F.linear(x, w, b)
+            da = (g * z * (z <= 0)).sum().reshape(1)
+            dz = torch.where(z > 0, g, alpha * g)
+        dw, db = dz.t() @ x, dz.sum(0)
+        if grads is not None:
+            dw, db = grads[0] + dw, grads[1] + db
+            da = None if da is None else grads[2] + da
+        return (dz @ w if want_dx else None), dw, (db if want_db or grads is not None else None), da
+
+    def linear_act(linear, x, active=None, dropout=None, residual=None):
+        return dense_fwd_raw(x, linear.weight, linear.bias, alpha=fused.prelu_slope(active), residual=residual)
+
+    ops.dense_fwd_raw, ops.dense_bwd_raw = dense_fwd_raw, dense_bwd_raw
+    ops.dense_bwd_ws = lambda n, K, D, device: None
     fused.linear_act = linear_act
-    fused.linear_sum = lambda l1, x1, l2, x2: l1(x1) + l2(x2)
     ops.modal_sum = lambda feats, alphas: torch.sum(
         torch.stack(feats, 0) * torch.softmax(alphas, 0).unsqueeze(-1).unsqueeze(-1), 0)
     ops.proj = lambda x, w, b, n_users: torch.cat([b.unsqueeze(0).expand(n_users, -1), F.linear(x, w, b)])

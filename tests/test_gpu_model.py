@@ -98,6 +98,7 @@ def test_graphed_train_step_matches_eager_steps():
     """The captured step replays the same arithmetic as the eager step (dropout off), and with
     dropout on every replay draws a different mask."""
     from recommend_amd.train_step import GraphedTrainStep
+    from recommend_amd.optim import FusedClipAdam
     from recommend_amd import ops
     U, I, D = 300, 200, 64
 
@@ -108,7 +109,9 @@ def test_graphed_train_step_matches_eager_steps():
         dp, di = sampler.device_csr(DEV)
         loader = TrainBatchLoader(tu, ti, tr, 256, sampler, shuffle=False, device=DEV, resolve_on_host=False)
         batches = [b for b in loader if b["user_ids"].shape[0] == 256][:6]
-        opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True, fused=fused)
+        # fused: the library's own clip + Adam kernel pair; otherwise torch's optimizer (the reference's)
+        opt = (FusedClipAdam(model.parameters(), lr=0.01) if fused
+               else torch.optim.Adam(model.parameters(), lr=0.01, capturable=True))
         model.train()
         return model, opt, batches, {"pos_ptr": dp, "pos_items": di}
 
@@ -123,7 +126,7 @@ def test_graphed_train_step_matches_eager_steps():
             torch.nn.utils.clip_grad_norm_(m1.parameters(), 1.0)
             o1.step()
             eager.append(float(loss))
-        m2, o2, batches2, consts2 = setup(0.0, fused=True)    # clipping folded into the fused update
+        m2, o2, batches2, consts2 = setup(0.0, fused=True)    # clipping inside the optimizer's own update kernels
         st = GraphedTrainStep(m2, o2, gather_dot_bpr_loss, batches2[0], constants=consts2, warmup_steps=1)
         graphed = [float(st(b)) for b in batches2]
         np.testing.assert_allclose(graphed, eager[1:], rtol=2e-4)
