@@ -114,6 +114,20 @@ int rk_deg_normalize_f32(const int32_t *rowptr, const int32_t *col,
                          const int32_t *eid, int32_t n_nodes,
                          float *w_norm_coo, void *stream);
 
+/* Feature-similarity edge weights (device).  Replaces GraphConstructor._compute_edge_weights,
+ * model/test/graph_constructor.py:137-156, for the COO edge list (src, dst):
+ *   RK_EDGE_SIM_COSINE       clamp(<x_s, x_d> / ((|x_s| + 1e-12)(|x_d| + 1e-12)), 0, 1)   (:144-147)
+ *   RK_EDGE_SIM_SIGMOID_DOT  sigmoid(<x_s, x_d>)                                          (:148-151)
+ * X holds the feature rows of nodes [row_lo, row_lo + n_rows) (F floats each, F % 4 == 0); every
+ * other node has all-zero features, as the reference's zero padding of a user- or item-side
+ * feature to all nodes makes them (:130-135).  fp32 fma chains per lane and a fixed reduction
+ * tree: bitwise reproducible, within 1e-6 of a float64 evaluation. */
+#define RK_EDGE_SIM_COSINE 0
+#define RK_EDGE_SIM_SIGMOID_DOT 1
+int rk_edge_feature_sim_f32(const int32_t *src, const int32_t *dst, int64_t nnz,
+                            const float *X, int32_t row_lo, int32_t n_rows,
+                            int32_t F, int32_t mode, float *out, void *stream);
+
 /* out[p] = src[idx[p]] (permutes COO-ordered edge values into CSR/CSC order) */
 int rk_gather_f32(const float *src, const int32_t *idx, int64_t n, float *out,
                   void *stream);

@@ -174,3 +174,17 @@ def build_item_graph(feat, k):
     score = (1.0 / (score.sum(1) + 1e-8))[:, None] * score
     dst, src = np.nonzero(score)
     return src, dst, score[dst, src]
+
+
+def edge_feature_weights(src, dst, x_padded, edge_weight_type):
+    """graph_constructor.py:137-156 in float64: x_padded is the feature matrix zero-padded to all
+    nodes (:130-135).  "cosine": clamp(<x_s,x_d> / ((|x_s|+1e-12)(|x_d|+1e-12)), 0, 1);
+    "dot": sigmoid(<x_s,x_d>)."""
+    x = np.asarray(x_padded, np.float64)
+    sim = np.einsum("ij,ij->i", x[src], x[dst])
+    if edge_weight_type == "cosine":
+        norm = np.linalg.norm(x, axis=1) + 1e-12
+        return np.clip(sim / (norm[src] * norm[dst]), 0.0, 1.0)
+    if edge_weight_type == "dot":
+        return 1.0 / (1.0 + np.exp(-sim))
+    raise ValueError(f"Unknown edge weight type: {edge_weight_type}")

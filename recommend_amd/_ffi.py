@@ -64,6 +64,7 @@ SIGNATURES = {
     "rk_in_weight_sqrt_f32": (c_int32, [P, P, P, c_int32, P, P]),
     "rk_sym_scale_rows_f32": (c_int32, [P, P, P, P, c_int32, c_int32, P, P, P]),
     "rk_deg_normalize_f32": (c_int32, [P, P, P, c_int32, P, P]),
+    "rk_edge_feature_sim_f32": (c_int32, [P, P, c_int64, P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "rk_gather_f32": (c_int32, [P, P, c_int64, P, P]),
     "rk_spmm_csr_f32": (c_int32, [P, P, P, c_int32, P, c_int32, P, P, c_float, c_float,
                                   POINTER(SpmmPlan), P]),

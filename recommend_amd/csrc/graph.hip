@@ -81,6 +81,57 @@ __global__ __launch_bounds__(256) void sym_norm_long_kernel(const int32_t *__res
   }
 }
 
+// ------------------------------------------------- feature-similarity edge weights -----
+// One wavefront per edge: the dot product of the two endpoints' feature rows and both squared
+// norms in one sweep (float4 per lane, lane-strided, a fixed shuffle tree: bitwise reproducible).
+// Nodes outside [row_lo, row_lo + n_rows) carry all-zero features (the zero padding of
+// graph_constructor.py:130-135): their rows are never read, dot and norm are 0.
+// mode 0: clamp(dot / ((|a| + 1e-12) (|b| + 1e-12)), 0, 1); mode 1: sigmoid(dot).
+__global__ __launch_bounds__(256) void edge_sim_kernel(const int32_t *__restrict__ src,
+                                                       const int32_t *__restrict__ dst, int64_t nnz,
+                                                       const float *__restrict__ X, int32_t row_lo, int32_t n_rows,
+                                                       int32_t F, int mode, float *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 4 + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (e >= nnz) return;
+  const int32_t a = src[e] - row_lo, b = dst[e] - row_lo;
+  const bool in_a = a >= 0 && a < n_rows, in_b = b >= 0 && b < n_rows;
+  float dot = 0.0f, na = 0.0f, nb = 0.0f;
+  if (in_a && in_b) {
+    const float4 *pa = reinterpret_cast<const float4 *>(X + (int64_t)a * F);
+    const float4 *pb = reinterpret_cast<const float4 *>(X + (int64_t)b * F);
+    for (int q = lane; q < F / 4; q += kWave) {
+      const float4 x = pa[q], y = pb[q];
+      dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot); dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
+      na = fmaf(x.x, x.x, na); na = fmaf(x.y, x.y, na); na = fmaf(x.z, x.z, na); na = fmaf(x.w, x.w, na);
+      nb = fmaf(y.x, y.x, nb); nb = fmaf(y.y, y.y, nb); nb = fmaf(y.z, y.z, nb); nb = fmaf(y.w, y.w, nb);
+    }
+  } else if (mode == 0 && (in_a || in_b)) {   // only the norm of the endpoint that has features (dot = 0 anyway)
+    const float4 *p = reinterpret_cast<const float4 *>(X + (int64_t)(in_a ? a : b) * F);
+    for (int q = lane; q < F / 4; q += kWave) {
+      const float4 x = p[q];
+      na = fmaf(x.x, x.x, na); na = fmaf(x.y, x.y, na); na = fmaf(x.z, x.z, na); na = fmaf(x.w, x.w, na);
+    }
+    if (!in_a) { nb = na; na = 0.0f; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dot += __shfl_xor(dot, off, kWave);
+    na += __shfl_xor(na, off, kWave);
+    nb += __shfl_xor(nb, off, kWave);
+  }
+  if (lane != 0) return;
+  float w;
+  if (mode == 0) {
+    const float sim = dot / ((sqrtf(na) + 1e-12f) * (sqrtf(nb) + 1e-12f));
+    w = fminf(fmaxf(sim, 0.0f), 1.0f);
+    if (sim != sim) w = sim;      // torch.clamp keeps a NaN
+  } else {
+    w = 1.0f / (1.0f + expf(-dot));
+  }
+  out[e] = w;
+}
+
 __global__ void deg_pow_kernel(const int32_t *__restrict__ rowptr, int32_t n,
                                float *__restrict__ dinv) {
   const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +214,20 @@ int rk_sym_normalize_f32(const int32_t *rowptr, const int32_t *col,
   const int rc = launch_in_weight_sqrt(rowptr, eid, w_coo, n_nodes, sqrt_in_w, st);
   if (rc != RK_OK) return rc;
   return launch_sym_scale(rowptr, col, eid, w_coo, sqrt_in_w, n_nodes, 0, w_norm_coo, st);
+}
+
+int rk_edge_feature_sim_f32(const int32_t *src, const int32_t *dst, int64_t nnz, const float *X, int32_t row_lo,
+                            int32_t n_rows, int32_t F, int32_t mode, float *out, void *stream) {
+  RK_CHECK_ARG(nnz >= 0 && n_rows >= 0 && row_lo >= 0, "negative size");
+  RK_CHECK_ARG(mode == RK_EDGE_SIM_COSINE || mode == RK_EDGE_SIM_SIGMOID_DOT, "unknown similarity mode");
+  RK_CHECK_ARG(F > 0 && F % 4 == 0, "feature width must be a positive multiple of 4");
+  if (nnz == 0) return RK_OK;
+  RK_CHECK_ARG(src && dst && out && (n_rows == 0 || X), "null pointer");
+  RK_CHECK_ARG(rk::aligned16(X), "feature rows must be 16-byte aligned");
+  edge_sim_kernel<<<(unsigned)rk::ceil_div(nnz, 4), 256, 0, (hipStream_t)stream>>>(src, dst, nnz, X, row_lo, n_rows, F,
+                                                                                    mode, out);
+  RK_CHECK_LAUNCH("edge_sim_kernel");
+  return RK_OK;
 }
 
 int rk_deg_normalize_f32(const int32_t *rowptr, const int32_t *col,

@@ -159,19 +159,17 @@ class GraphConstructor:
             raise ValueError(f"Unknown edge weight type: {self.edge_weight_type}")
         self._ensure_on_device()
         g = self.graph
-        x = self._node_feature(feature).to(g.device, torch.float32)
-        src = torch.from_numpy(g.src).to(g.device, torch.int64)
-        dst = torch.from_numpy(g.dst).to(g.device, torch.int64)
-        out = torch.empty(src.shape[0], dtype=torch.float32, device=g.device)
-        norm = torch.norm(x, dim=1) + 1e-12 if self.edge_weight_type == "cosine" else None
-        step = 1 << 16
-        for b in range(0, src.shape[0], step):
-            s, d = src[b:b + step], dst[b:b + step]
-            sim = torch.sum(x[s] * x[d], dim=1)
-            if norm is not None:
-                out[b:b + step] = torch.clamp(sim / (norm[s] * norm[d]), 0, 1)
-            else:
-                out[b:b + step] = torch.sigmoid(sim)
+        # the zero-padded rows of _node_feature are never materialised: the kernel is told which
+        # node range carries features
+        if feature in self.user_features:
+            rows, row_lo = self.user_features[feature], 0
+        elif feature in self.item_features:
+            rows, row_lo = self.item_features[feature], self.num_users
+        else:
+            raise KeyError(feature)
+        src = torch.from_numpy(g.src).to(g.device)
+        dst = torch.from_numpy(g.dst).to(g.device)
+        out = ops.edge_feature_sim(src, dst, rows.to(g.device, torch.float32), row_lo, self.edge_weight_type)
         g.edata[f"{feature}_weight"] = out
 
     def _normalize_graph(self, feature=None):

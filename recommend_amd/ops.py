@@ -224,6 +224,21 @@ def sym_scale_rows(mat, w_local, row_offset, sqrt_in_w):
     return out
 
 
+def edge_feature_sim(src, dst, x_rows, row_lo, mode):
+    """Per-edge feature similarity (graph_constructor.py:137-156): x_rows are the features of nodes
+    [row_lo, row_lo + len(x_rows)), all other nodes have zero features.  mode: "cosine" | "dot"."""
+    _need_cuda(src, dst, x_rows)
+    x_rows = _f32c(x_rows)
+    src, dst = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+    if x_rows.shape[1] % 4:
+        x_rows = torch.nn.functional.pad(x_rows, (0, 4 - x_rows.shape[1] % 4))   # zero columns change nothing
+    out = torch.empty(src.shape[0], dtype=torch.float32, device=src.device)
+    _ffi.call("rk_edge_feature_sim_f32", ptr(src), ptr(dst), c_int64(src.shape[0]), ptr(x_rows), c_int32(int(row_lo)),
+              c_int32(x_rows.shape[0]), c_int32(x_rows.shape[1]), c_int32({"cosine": 0, "dot": 1}[mode]), ptr(out),
+              stream_ptr(src.device))
+    return out
+
+
 def deg_normalize(mat):
     """w_e = deg_in[src]^-0.5 * deg_in[dst]^-0.5 in COO order."""
     out = torch.empty(mat.nnz, dtype=torch.float32, device=mat.device)

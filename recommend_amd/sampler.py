@@ -89,11 +89,17 @@ class TrainBatchLoader:
     Shuffle order: the reference wraps a torch DataLoader(shuffle=True); creating
     its iterator draws one int64 (the loader's base seed) and the RandomSampler
     draws a second one to seed the generator behind torch.randperm.  The same two
-    draws are made here so a run seeded like the reference sees the same batches
-    (num_workers=0 behaviour)."""
+    draws are made here so a run seeded like the reference sees the same batches.
+
+    num_workers = 0: negatives come from the process-wide `random` stream, batch after batch
+    (the sampler's own state, seeded like main.set_seed seeds `random`).
+    num_workers = W > 0 (the reference's preset is 4, config.py:30): torch's DataLoader hands
+    batch b to worker b mod W, and every worker process starts with random.seed(base_seed + w)
+    (torch/utils/data/_utils/worker.py), base_seed being the first of the two draws above; new
+    workers, hence new seeds, every epoch.  The W streams are reproduced here in one process."""
 
     def __init__(self, users, items, ratings, batch_size, sampler=None, shuffle=True,
-                 device=None, resolve_on_host=True):
+                 device=None, resolve_on_host=True, num_workers=0):
         self.users = torch.as_tensor(np.asarray(users), dtype=torch.int64)
         self.items = torch.as_tensor(np.asarray(items), dtype=torch.int64)
         self.ratings = None if ratings is None else torch.as_tensor(np.asarray(ratings), dtype=torch.float32)
@@ -102,22 +108,34 @@ class TrainBatchLoader:
         self.shuffle = shuffle
         self.device = device
         self.resolve_on_host = resolve_on_host
+        self.num_workers = int(num_workers)
 
     def __len__(self):
         return (self.users.shape[0] + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
         n = self.users.shape[0]
+        # the iterator's base seed is drawn whether or not the loader shuffles
+        base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
         if self.shuffle:
-            torch.empty((), dtype=torch.int64).random_()          # DataLoader base seed
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             g = torch.Generator()
             g.manual_seed(seed)
             order = torch.randperm(n, generator=g)
         else:
             order = torch.arange(n)
-        for b in range(0, n, self.batch_size):
+        worker_states = None
+        if self.num_workers > 0 and self.sampler is not None:
+            worker_states = []
+            for w in range(self.num_workers):
+                st = np.zeros(625, np.uint32)
+                _ffi.call("rk_mt_seed_host", ptr(st), _ffi.c_uint64(base_seed + w))
+                worker_states.append(st)
+            own_state = self.sampler.state
+        for bi, b in enumerate(range(0, n, self.batch_size)):
             idx = order[b:b + self.batch_size]
+            if worker_states is not None:
+                self.sampler.state = worker_states[bi % self.num_workers]
             batch = {"user_ids": self.users[idx], "item_ids": self.items[idx]}
             if self.ratings is not None:
                 batch["ratings"] = self.ratings[idx]
@@ -126,6 +144,8 @@ class TrainBatchLoader:
                 batch["neg_rank"] = torch.from_numpy(ranks)
                 if neg is not None:
                     batch["neg_items"] = torch.from_numpy(neg)
+            if worker_states is not None:
+                self.sampler.state = own_state
             if self.device is not None:
                 batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
             yield batch

@@ -204,18 +204,20 @@ def golden_loader():
         np.save(os.path.join(tmp, "item_image_feat.npy"), rng.standard_normal((I, 8)).astype(np.float32))
         out = {"users": pairs[:, 0], "items": pairs[:, 1], "rating": rating.astype(np.float32),
                "label": label, "n_users": np.array(U), "n_items": np.array(I)}
-        for neg_ratio, bs in [(1, 64), (3, 50), (8, 32)]:
+        # (neg_ratio, batch size, DataLoader workers): 0 workers and the reference's preset of 4
+        # (config.py:30), where batch b is collated in worker b mod 4
+        for neg_ratio, bs, workers in [(1, 64, 0), (3, 50, 0), (8, 32, 0), (1, 32, 4), (2, 48, 4)]:
             cfg = ref_config.get_config("baby")
             cfg.data.data_path = tmp
             cfg.data.num_users, cfg.data.num_items = U, I
-            cfg.data.batch_size, cfg.data.num_workers, cfg.data.neg_ratio = bs, 0, neg_ratio
+            cfg.data.batch_size, cfg.data.num_workers, cfg.data.neg_ratio = bs, workers, neg_ratio
             cfg.system.device = "cpu"
             # main.set_seed (main.py:31-39)
             random.seed(42)
             np.random.seed(42)
             torch.manual_seed(42)
             train_loader, val_loader, test_loader = create_data_loaders(cfg)
-            tag = f"r{neg_ratio}_b{bs}"
+            tag = f"r{neg_ratio}_b{bs}" + (f"_w{workers}" if workers else "")
             ds = train_loader.dataset
             out[f"{tag}/train_users"] = ds.df[cfg.data.user_col].to_numpy()
             out[f"{tag}/train_items"] = ds.df[cfg.data.item_col].to_numpy()

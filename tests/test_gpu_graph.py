@@ -167,3 +167,44 @@ def test_spmm_argument_errors():
         gc.propagate(torch.randn(20, 20, device=DEV))
     with pytest.raises(RkError):
         gc.propagate(torch.randn(20, 64))          # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("kind", ["cosine", "dot"])
+@pytest.mark.parametrize("F", [384, 4096, 30])
+def test_feature_similarity_edge_weights_vs_float64(kind, F):
+    """rk_edge_feature_sim_f32 (one wavefront per edge) against the float64 restatement of
+    graph_constructor.py:137-156, on an edge list with both endpoints inside, one endpoint inside
+    and no endpoint inside the node range that carries features; then the same through
+    GraphConstructor.creat_feature_weight on a bipartite graph with item-side features."""
+    import torch
+    from recommend_amd import ops
+    rng = np.random.default_rng(F)
+    n_nodes, row_lo, n_rows, nnz = 500, 120, 300, 20000
+    x = (rng.standard_normal((n_rows, F)) * (0.2 if kind == "dot" else 1.0)).astype(np.float32)
+    x[7] = 0.0                                           # an all-zero feature row inside the range
+    src = rng.integers(0, n_nodes, nnz).astype(np.int32)
+    dst = rng.integers(0, n_nodes, nnz).astype(np.int32)
+    dst[:200] = src[:200]                                # self loops: cosine exactly 1 up to rounding
+    padded = np.zeros((n_nodes, F), np.float32)
+    padded[row_lo:row_lo + n_rows] = x
+    want = graph_oracle.edge_feature_weights(src, dst, padded, kind)
+    got = ops.edge_feature_sim(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV),
+                               torch.from_numpy(x).to(DEV), row_lo, kind).cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-6
+    again = ops.edge_feature_sim(torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV),
+                                 torch.from_numpy(x).to(DEV), row_lo, kind).cpu().numpy()
+    assert np.array_equal(got, again)                    # no atomics: bitwise reproducible
+
+    if F == 384:
+        U, I = 90, 60
+        d = synth.make_interactions(U, I, 700, seed=3)
+        tu, ti, tr = d.split(0)
+        feat = torch.from_numpy(rng.standard_normal((I, F)).astype(np.float32))
+        gc = GraphConstructor(item_features={"text": feat}, edge_weight_type=kind, normalize_adj=False)
+        gc.build_graph((tu, ti, tr), U, I)
+        gc.creat_feature_weight("text")
+        g = gc.graph
+        pad = np.zeros((U + I, F), np.float32)
+        pad[U:] = feat.numpy()
+        want = graph_oracle.edge_feature_weights(g.src, g.dst, pad, kind)
+        assert np.abs(g.edata["text_weight"].cpu().numpy() - want).max() <= 2e-6

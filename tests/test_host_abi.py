@@ -135,17 +135,21 @@ def test_negative_sampler_bit_exact_vs_python_random(R):
 
 def test_batches_bit_exact_vs_reference_loader(golden):
     """Shuffle order, batch contents and negative items equal what the reference's
-    GraphDataLoader produced (num_workers=0) for two epochs and three settings."""
+    GraphDataLoader produced for two epochs: three settings with num_workers=0, two with the
+    reference's preset of four workers (batch b collated in worker b mod 4, each worker's `random`
+    seeded base_seed + worker id)."""
     z = golden("loader_batches.npz")
     U, I = int(z["n_users"]), int(z["n_items"])
     p, it = build_user_csr(z["users"], z["items"], U)          # positives over the FULL table
     label = z["label"]
     tr = label == 0
-    for tag, R, bs in (("r1_b64", 1, 64), ("r3_b50", 3, 50), ("r8_b32", 8, 32)):
+    for tag, R, bs, workers in (("r1_b64", 1, 64, 0), ("r3_b50", 3, 50, 0), ("r8_b32", 8, 32, 0),
+                                ("r1_b32_w4", 1, 32, 4), ("r2_b48_w4", 2, 48, 4)):
         np.testing.assert_array_equal(z["users"][tr], z[f"{tag}/train_users"])
         random.seed(42), np.random.seed(42), torch.manual_seed(42)
         sampler = NegativeSampler(p, it, I, seed=42, neg_ratio=R)
-        loader = TrainBatchLoader(z["users"][tr], z["items"][tr], z["rating"][tr], bs, sampler)
+        loader = TrainBatchLoader(z["users"][tr], z["items"][tr], z["rating"][tr], bs, sampler,
+                                  num_workers=workers)
         for e in range(2):
             batches = list(loader)
             assert len(batches) == int(z[f"{tag}/e{e}/n_batches"]) == len(loader)
