@@ -41,13 +41,42 @@ from recommend_amd.train_step import GraphedTrainStep  # noqa: E402
 METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
 K_LIST = [5, 10, 20]
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
-# Memory-side bytes per launch at the Elec shape from rocprofv3 PMC passes (FETCH_SIZE doubled as gfx950
-# requires for 16-B-per-lane reads, plus WRITE_SIZE; one counter per run): profiles/r01_pmc_*.csv.
-# They are measurements of THIS shape on one GPU; other shapes report null.
-PMC_TRAFFIC_ELEC = {"score_topk": 2 * 687.0e6 + 207.2e6, "spmm": 2 * 252.3e6 + 63.9e6}
+# Memory-side bytes per launch come from rocprofv3 PMC passes over THIS program (`--pmc-pass`, one
+# counter per run: tools/pmc_bench.sh), summarised by tools/pmc_traffic.py into the newest
+# profiles/r*_pmc_traffic.json.  The summary names the workload and a digest of the kernel sources it
+# was collected from; a line measured on another workload or on changed sources reports null.
 MFMA_F32_PEAK_TFS = 157.3    # MI355X fp32 matrix peak
 MFMA_F16_PEAK_TFS = 2500.0   # MI355X dense fp16 / bf16 matrix peak
 BATCH = {"baby": 2048, "clothing": 1024, "sports": 256, "elec": 256}   # reference config.py presets
+
+
+def kernel_source_digest():
+    """sha256 over the kernel sources, so counter summaries can be tied to the code they measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "recommend_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(group, shape, D, world):
+    """(bytes per launch, file it came from) of a kernel group from the newest counter summary, or
+    (None, reason) when there is none for this workload and these sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_traffic.json"
+    name = os.path.relpath(files[-1], ROOT)
+    with open(files[-1]) as f:
+        doc = json.load(f)
+    if doc.get("shape") != shape or doc.get("emb_dim") != D or world != 1:
+        return None, f"{name} was collected on {doc.get('shape')} / emb_dim {doc.get('emb_dim')} / 1 GPU"
+    if doc.get("kernel_source_digest") != kernel_source_digest():
+        return None, f"{name} was collected from other kernel sources ({doc.get('kernel_source_digest')})"
+    return doc["groups"][group]["traffic_bytes"], name
 
 
 def log(*a):
@@ -146,7 +175,13 @@ def main():
                     help="training steps to time for the epoch figure (-1: the whole epoch, 0: skip)")
     ap.add_argument("--cpu-users", type=int, default=8192, help="users in the CPU baseline sample (0: skip)")
     ap.add_argument("--dropout", type=float, default=0.3)
+    ap.add_argument("--spmm-reps", type=int, default=200, help="SpMM launches per timing")
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="short run for a rocprofv3 --pmc pass: few repetitions, no exact-kernel, epoch or CPU leg; "
+                         "prints how many calls of each kind were made so counters can be divided per call")
     args = ap.parse_args()
+    if args.pmc_pass:
+        args.steps, args.warmup, args.epoch_steps, args.cpu_users, args.spmm_reps = 2, 0, 0, 0, 5
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,22 +261,24 @@ def main():
     topk_fn = (lambda: ev.topk(ue, ie, 20)) if world == 1 else (lambda: ev.local_topk(ue, ie, 20))
     topk_fn()
     ms_topk = event_ms(topk_fn, max(3, args.steps))
+    topk_calls = args.warmup + args.steps + 1 + max(3, args.steps)
     flop = 2.0 * U * n_loc * D
     tflops = flop / (ms_topk * 1e-3) / 1e12
     filtered = U * n_loc >= (1 << 29) and D in (64, 128)   # what rk_score_topk_f32 decides
     peak = MFMA_F16_PEAK_TFS if filtered else MFMA_F32_PEAK_TFS
+    traffic_topk, traffic_topk_src = pmc_traffic("score_topk_call", args.shape, D, world)
     roofline = {"kernel": ("score_topk_kernel<fp16 filter> + merge + refine + exact fallback (one rk_score_topk_f32 call)"
                            if filtered else "score_topk_kernel (+topk_merge_kernel)"),
                 "bound": "mfma", "achieved": round(tflops, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(tflops / peak, 4),
-                "traffic": PMC_TRAFFIC_ELEC["score_topk"] if (args.shape == "elec" and world == 1 and D == 64) else None,
+                "traffic": traffic_topk, "traffic_source": traffic_topk_src,
                 "traffic_unit": "B per call (L2 memory-side requests, Infinity-Cache hits included)",
                 "ms_per_launch": round(ms_topk, 4),
                 "algorithmic": f"2*U*I*D = {flop:.4g} flop per call",
                 "note": ("peak is the dense fp16 MFMA rate, the arithmetic of the dominant kernel; that kernel is bound "
                          "by the vector instructions of the top-K selection, not by the matrix pipe" if filtered else "")}
     roofline_exact = None
-    if world == 1:
+    if world == 1 and not args.pmc_pass:
         exact_fn = lambda: ev.topk(ue, ie, 20, mode="exact")
         exact_fn()
         ms_exact = event_ms(exact_fn, max(3, args.steps))
@@ -256,16 +293,17 @@ def main():
     gc.graph.refresh_values("weight")
     spmm_fn = lambda: ops.spmm_raw(gc.graph.fwd, h, out=buf)
     spmm_fn()
-    ms_spmm = event_ms(spmm_fn, 200)
+    ms_spmm = event_ms(spmm_fn, args.spmm_reps)
+    traffic_spmm, traffic_spmm_src = pmc_traffic("spmm_hop", args.shape, D, 1)
     spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * D * 4
     gbs = spmm_bytes / (ms_spmm * 1e-3) / 1e9
     roofline_spmm = {"kernel": "spmm_rows_kernel (+spmm_multi_reduce_kernel)", "bound": "hbm",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "traffic": PMC_TRAFFIC_ELEC["spmm"] if (args.shape == "elec" and D == 64) else None,
+                     "traffic": traffic_spmm, "traffic_source": traffic_spmm_src,
                      "ms_per_launch": round(ms_spmm, 5),
                      "algorithmic": f"nnz*8 + (N+1)*4 + 2*N*D*4 = {spmm_bytes} B per hop"}
-    ms_spmm_t = event_ms(lambda: ops.spmm_raw(gc.graph.bwd, h, out=buf), 200)
+    ms_spmm_t = event_ms(lambda: ops.spmm_raw(gc.graph.bwd, h, out=buf), args.spmm_reps)
 
     # ---------------------------------------------------------------- one training epoch
     epoch = None
@@ -310,7 +348,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_users > 0:
         v, dt, cores, n = cpu_baseline_eval(ue.cpu().numpy(), ie.cpu().numpy(), (tu, ti), (vu, vi), args.cpu_users)
-        cpu = {"value": round(v, 1), "unit": "users/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(v, 1), "unit": "users/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
                "sample": f"reference-style verify (matmul, index_put -1e10, topk x3, metrics) on the first {n} "
                          f"users x {I} items in chunks of {args.cpu_users}, {dt:.2f} s"}
         if epoch is not None:
@@ -398,7 +436,10 @@ def main():
             "spmm_transpose_ms": round(ms_spmm_t, 5),
             "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
             "recall@20": round(float(res["recall@20"]), 6),
+            "kernel_source_digest": kernel_source_digest(),
         }
+        if args.pmc_pass:
+            line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
         if sharded_hop is not None:
             line["row_sharded_hop"] = sharded_hop
         if sharded_train is not None:
