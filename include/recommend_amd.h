@@ -145,6 +145,9 @@ typedef struct rk_spmm_plan {
   const int32_t *multi_slot_ptr;  /* [n_multi+1] slot range of each           */
   int32_t n_slots;
   float *partial;                 /* [n_slots * D] scratch, caller-owned      */
+  int32_t *arrive;                /* [n_multi] arrival counters, zeroed ONCE by the
+                                   * caller; every launch leaves them zero.  Launches
+                                   * that share a plan must not overlap.            */
 } rk_spmm_plan;
 
 /* Replaces update_all(fn.u_mul_e('h','weight','m'), fn.sum('m','h')),
@@ -424,6 +427,21 @@ size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K);
 int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items,
                      int64_t ld, int32_t K, float *out_scores, int32_t *out_ids,
                      void *ws, size_t ws_bytes, void *stream);
+
+/* ---- (f).4: similarity + top-K over wide feature rows (device) ------------- */
+/* Replaces the dense pipeline of the item-item kNN graph, model/sgrec/graph.py:
+ * 100-105 (score = normalized_feat @ normalized_feat.T; torch.topk(score, k)):
+ * out[a] = the K largest <A[a, :], B[b, :]> over b (score descending, ties by
+ * lower b) for A[n_a, F], B[n_b, F] row-major fp32, F a multiple of 64 (pad with
+ * zero columns), without holding any block of the score matrix.  Scores are exact
+ * fp32 products accumulated in fp32 along the width.  No mask: a row of A that is
+ * also a row of B ranks itself, as the reference's graph does.
+ * 1 <= K <= min(n_b, 32).  ws: rk_score_topk_wide_ws_bytes(). */
+size_t rk_score_topk_wide_ws_bytes(int32_t n_a, int32_t n_b, int32_t K);
+int rk_score_topk_wide_f32(const float *A, int32_t n_a, const float *B,
+                           int32_t n_b, int32_t F, int32_t K, float *out_scores,
+                           int32_t *out_ids, void *ws, size_t ws_bytes,
+                           void *stream);
 
 /* ---- M: ranking metrics (device) ---------------------------------------- */
 /* Replaces evaluate_all_at_k, evalue/metric.py:106-164, for every k in k_list

@@ -47,6 +47,7 @@ class SpmmPlan(Structure):
         ("multi_slot_ptr", c_void_p),
         ("n_slots", c_int32),
         ("partial", c_void_p),
+        ("arrive", c_void_p),
     ]
 
 
@@ -107,6 +108,8 @@ SIGNATURES = {
                                              P, P, P, c_size_t, P]),
     "rk_topk_merge_f32": (c_int32, [P, P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     "rk_rows_topk_ws_bytes": (c_size_t, [c_int32, c_int32]),
+    "rk_score_topk_wide_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rk_score_topk_wide_f32": (c_int32, [P, c_int32, P, c_int32, c_int32, c_int32, P, P, P, c_size_t, P]),
     "rk_rows_topk_f32": (c_int32, [P, c_int32, c_int32, c_int64, c_int32, P, P, P, c_size_t, P]),
     "rk_rank_metrics_ws_bytes": (c_size_t, [c_int32, c_int32]),
     "rk_rank_metrics_f32": (c_int32, [P, c_int32, c_int32, P, P, P, c_int32, P, P, P, c_int64,

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librecommend_amd.so")
-SOURCES = ["host.cpp", "graph.hip", "spmm.hip", "dense.hip", "dense_wide.hip", "glue.hip", "optim.hip", "bpr.hip", "eval.hip", "eval_filter.hip", "proj.hip"]
+SOURCES = ["host.cpp", "graph.hip", "spmm.hip", "dense.hip", "dense_wide.hip", "glue.hip", "optim.hip", "bpr.hip", "eval.hip", "eval_filter.hip", "knn.hip", "proj.hip"]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-fno-fast-math", "-ffp-contract=off",

@@ -12,8 +12,11 @@
 // whole workgroups: a chunk of up to kChunk edges per workgroup, its 256/LPR
 // groups each taking a contiguous slice, folded through LDS in a fixed order.
 // A row that is a single chunk is stored directly; longer rows store one
-// partial row per chunk and a second small launch (one wavefront per such row)
-// adds the partials in chunk order.  Long chunks are scheduled first.  No float
+// partial row per chunk, and the workgroup that finishes a row's last outstanding
+// chunk (an arrival counter per such row; partials are stored and re-read with
+// agent-scope accesses that go through to memory, so no cache write-back or
+// invalidate is involved) adds the partials in slot order, whichever chunk that
+// workgroup happened to hold.  Long chunks are scheduled first.  No float
 // atomics anywhere: the result is bitwise reproducible.
 #include "common.h"
 
@@ -113,12 +116,30 @@ __device__ __forceinline__ void store_row(float4 *__restrict__ out4, const float
   out4[row * LPR + sub] = acc;
 }
 
+// A float4 as two 8-byte agent-scope relaxed atomic accesses: the stores are written through to
+// memory and the loads are served from there, whichever CU and XCD the two sides run on.
+__device__ __forceinline__ void store_through(float4 *p, const float4 &v) {
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+  const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+  const unsigned long long hi = (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32);
+  __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_through(const float4 *p) {
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<float4 *>(p));
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
+
 constexpr int kChunk = 2048;  // edges per long-tier workgroup (matches rk_spmm_plan_host)
 
 struct PlanArgs {
-  int32_t long_thresh, n_chunks;
-  const int32_t *chunk_row, *chunk_begin, *chunk_end, *chunk_slot;
+  int32_t long_thresh, n_chunks, n_multi;
+  const int32_t *chunk_row, *chunk_begin, *chunk_end, *chunk_slot, *multi_slot_ptr;
   float4 *partial4;
+  int32_t *arrive;
 };
 
 template <int LPR, int AXPBY>
@@ -151,40 +172,62 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
   accumulate_edges<LPR>(col, val, h4, b, e, sub, acc);
   red[grp][sub] = acc;
   __syncthreads();
+  const int32_t slot = pl.chunk_slot[chunk];    // uniform over the workgroup
   if (grp == 0) {
     float4 s = red[0][sub];
 #pragma unroll
     for (int g = 1; g < GROUPS; ++g) add4(s, red[g][sub]);
-    const int32_t slot = pl.chunk_slot[chunk];
     if (slot < 0)
       store_row<LPR, AXPBY>(out4, h04, pl.chunk_row[chunk], sub, s, alpha, beta);
     else
-      pl.partial4[(int64_t)slot * LPR + sub] = s;
+      store_through(&pl.partial4[(int64_t)slot * LPR + sub], s);
   }
-}
-
-// one wavefront per row that was cut into several chunks
-template <int LPR, int AXPBY>
-__global__ __launch_bounds__(256) void spmm_multi_reduce_kernel(
-    const int32_t *__restrict__ multi_rows, const int32_t *__restrict__ multi_slot_ptr,
-    int32_t n_multi, const float4 *__restrict__ partial4, float4 *__restrict__ out4,
-    const float4 *__restrict__ h04, float alpha, float beta) {
-  constexpr int GPW = kWave / LPR;
-  const int lane = threadIdx.x % kWave;
-  const int sub = lane % LPR, g = lane / LPR;
-  const int32_t i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-  if (i >= n_multi) return;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int32_t s = multi_slot_ptr[i] + g; s < multi_slot_ptr[i + 1]; s += GPW)
-    add4(acc, partial4[(int64_t)s * LPR + sub]);
+  if (slot < 0) return;
+  // One chunk of a row cut into several.  The partial went out with write-through stores; once
+  // every wavefront has drained its stores one thread counts this chunk in.  Whoever draws the
+  // last ticket of the row sums the row's slots: it resets the counter for the next launch, and
+  // one wavefront reads the slots back (loads that bypass this CU's L1 and this XCD's view of
+  // other XCDs' lines) and adds them exactly as a separate launch over finished partials would
+  // (GPW lane groups striding the slots, then a fixed shuffle tree), so the bits do not depend on
+  // which chunk came last.  A release/acquire fence pair would do as well, but at agent scope
+  // the release writes back the whole L2 -- with the output rows of the hop in it -- once per chunk.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                              // also: everybody is done reading red[]
+  int32_t *flag = reinterpret_cast<int32_t *>(&red[0][0]);
+  if (tid == 0) {
+    int32_t lo = 0, hi = pl.n_multi;            // multi_slot_ptr[lo] <= slot < multi_slot_ptr[lo + 1]
+    while (hi - lo > 1) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (pl.multi_slot_ptr[mid] <= slot)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int32_t n_row_chunks = pl.multi_slot_ptr[lo + 1] - pl.multi_slot_ptr[lo];
+    const int32_t ticket = __hip_atomic_fetch_add(&pl.arrive[lo], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == n_row_chunks - 1;
+    if (last) __hip_atomic_store(&pl.arrive[lo], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag[0] = last ? lo : -1;
+  }
+  __syncthreads();
+  const int32_t mi = flag[0];
+  if (mi < 0 || tid >= kWave) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the loads below the ticket
+  {
+    constexpr int GPW = kWave / LPR;
+    const int g = tid / LPR;                    // tid < kWave here
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int32_t sl = pl.multi_slot_ptr[mi] + g; sl < pl.multi_slot_ptr[mi + 1]; sl += GPW)
+      add4(acc, load_through(&pl.partial4[(int64_t)sl * LPR + sub]));
 #pragma unroll
-  for (int off = LPR; off < kWave; off <<= 1) {
-    acc.x += __shfl_xor(acc.x, off, kWave);
-    acc.y += __shfl_xor(acc.y, off, kWave);
-    acc.z += __shfl_xor(acc.z, off, kWave);
-    acc.w += __shfl_xor(acc.w, off, kWave);
+    for (int off = LPR; off < kWave; off <<= 1) {
+      acc.x += __shfl_xor(acc.x, off, kWave);
+      acc.y += __shfl_xor(acc.y, off, kWave);
+      acc.z += __shfl_xor(acc.z, off, kWave);
+      acc.w += __shfl_xor(acc.w, off, kWave);
+    }
+    if (g == 0) store_row<LPR, AXPBY>(out4, h04, pl.chunk_row[chunk], sub, acc, alpha, beta);
   }
-  if (g == 0) store_row<LPR, AXPBY>(out4, h04, multi_rows[i], sub, acc, alpha, beta);
 }
 
 template <int LPR, int AXPBY>
@@ -201,19 +244,14 @@ int launch_spmm(const int32_t *rowptr, const int32_t *col, const float *val, int
   pl.chunk_end = has_long ? plan->chunk_end : nullptr;
   pl.chunk_slot = has_long ? plan->chunk_slot : nullptr;
   pl.partial4 = has_long ? reinterpret_cast<float4 *>(plan->partial) : nullptr;
+  pl.n_multi = has_long ? plan->n_multi : 0;
+  pl.multi_slot_ptr = has_long ? plan->multi_slot_ptr : nullptr;
+  pl.arrive = has_long ? plan->arrive : nullptr;
   const int64_t blocks = rk::ceil_div(n_rows, GROUPS) + pl.n_chunks;
   spmm_rows_kernel<LPR, AXPBY><<<(unsigned)blocks, 256, 0, st>>>(
       rowptr, col, val, n_rows, reinterpret_cast<const float4 *>(h),
       reinterpret_cast<float4 *>(out), reinterpret_cast<const float4 *>(h0), alpha, beta, pl);
   RK_CHECK_LAUNCH("spmm_rows_kernel");
-  if (has_long && plan->n_multi > 0) {
-    spmm_multi_reduce_kernel<LPR, AXPBY>
-        <<<(unsigned)rk::ceil_div(plan->n_multi, 256 / kWave), 256, 0, st>>>(
-            plan->multi_rows, plan->multi_slot_ptr, plan->n_multi,
-            reinterpret_cast<const float4 *>(plan->partial), reinterpret_cast<float4 *>(out),
-            reinterpret_cast<const float4 *>(h0), alpha, beta);
-    RK_CHECK_LAUNCH("spmm_multi_reduce_kernel");
-  }
   return RK_OK;
 }
 
@@ -279,9 +317,9 @@ int rk_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
                      plan->long_thresh > 0,
                  "incomplete spmm plan");
     RK_CHECK_ARG(plan->n_multi == 0 ||
-                     (plan->multi_rows && plan->multi_slot_ptr && plan->partial &&
+                     (plan->multi_rows && plan->multi_slot_ptr && plan->partial && plan->arrive &&
                       rk::aligned16(plan->partial)),
-                 "spmm plan has multi-chunk rows but no 16-byte aligned partial buffer");
+                 "spmm plan has multi-chunk rows but no 16-byte aligned partial buffer or no arrival counters");
   }
   hipStream_t st = (hipStream_t)stream;
   switch (D) {

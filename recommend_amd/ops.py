@@ -128,13 +128,15 @@ class CsrMatrix:
             return None, None
         part = self._partial.get(D)
         if part is None:
-            part = torch.empty(max(self.n_slots, 1) * D, dtype=torch.float32, device=self.device)
+            # partial rows of the chunks of multi-chunk rows + their arrival counters (zero between launches)
+            part = (torch.empty(max(self.n_slots, 1) * D, dtype=torch.float32, device=self.device),
+                    torch.zeros(max(self.n_multi, 1), dtype=torch.int32, device=self.device))
             self._partial[D] = part
         d = self._plan_dev
         p = _ffi.SpmmPlan(self.LONG_THRESH, self.n_chunks, d["chunk_row"].data_ptr(),
                           d["chunk_begin"].data_ptr(), d["chunk_end"].data_ptr(),
                           d["chunk_slot"].data_ptr(), self.n_multi, d["multi_rows"].data_ptr(),
-                          d["multi_slot_ptr"].data_ptr(), self.n_slots, part.data_ptr())
+                          d["multi_slot_ptr"].data_ptr(), self.n_slots, part[0].data_ptr(), part[1].data_ptr())
         return p, part
 
 
@@ -575,6 +577,31 @@ def rows_topk(scores, K):
     _ffi.call("rk_rows_topk_f32", ptr(scores), c_int32(n_rows), c_int32(n_items), c_int64(scores.stride(0)),
               c_int32(K), ptr(out_s), ptr(out_i), ptr(ws), c_size_t(ws.numel() * 4),
               stream_ptr(scores.device))
+    return out_s, out_i
+
+
+def score_topk_wide(A, B, K):
+    """The K largest <A[a], B[b]> over b for every row a of A (score descending, ties by lower
+    b), for feature rows of any width: the width is zero-padded to a multiple of 64 and walked in
+    chunks inside the kernel, no block of A @ B.T exists.  model/sgrec/graph.py:102-105.
+    Returns (values [n_a, K] fp32, ids [n_a, K] int32)."""
+    _need_cuda(A, B)
+    A, B = _f32c(A.detach()), _f32c(B.detach())
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[1]:
+        raise ValueError("score_topk_wide: A [n_a, F] and B [n_b, F] must share the width")
+    F = A.shape[1]
+    if F % 64:
+        same = A.data_ptr() == B.data_ptr()
+        A = torch.nn.functional.pad(A, (0, 64 - F % 64))
+        B = A if same else torch.nn.functional.pad(B, (0, 64 - F % 64))
+    n_a, n_b = A.shape[0], B.shape[0]
+    lib = _ffi.load()
+    ws_bytes = lib.rk_score_topk_wide_ws_bytes(n_a, n_b, K)
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=A.device)
+    out_s = torch.empty((n_a, K), dtype=torch.float32, device=A.device)
+    out_i = torch.empty((n_a, K), dtype=torch.int32, device=A.device)
+    _ffi.call("rk_score_topk_wide_f32", ptr(A), c_int32(n_a), ptr(B), c_int32(n_b), c_int32(A.shape[1]), c_int32(K),
+              ptr(out_s), ptr(out_i), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(A.device))
     return out_s, out_i
 
 

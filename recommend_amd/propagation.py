@@ -130,14 +130,14 @@ class IU_GCN(nn.Module):
         return h
 
 
-def build_item_graph(feat: torch.Tensor, k: int, weight_key: str, chunk_rows: int = 8192) -> DeviceGraph:
+def build_item_graph(feat: torch.Tensor, k: int, weight_key: str) -> DeviceGraph:
     """Item-item kNN graph of model/sgrec/graph.py:100-118 (build_item_g) without the dense
-    I x I matrices: cosine similarities of one block of rows at a time (a library GEMM), the k
-    largest of each row by rk_rows_topk_f32 (ties: lower item id), weights s / (sum of the
-    row's k similarities + 1e-8).  Edges run from the neighbour (src) to the row item (dst),
-    ordered by (dst, src) as score.nonzero() lists them; exact-zero similarities are dropped
-    as nonzero() drops them.  feat: [I, F] on the GPU.  Returns the graph with
-    edata[weight_key] set."""
+    I x I matrices: cosine similarities and the k largest of each row come out of one fused
+    kernel (rk_score_topk_wide_f32: the feature width is a loop inside it; ties: lower item id),
+    weights s / (sum of the row's k similarities + 1e-8).  Edges run from the neighbour (src) to
+    the row item (dst), ordered by (dst, src) as score.nonzero() lists them; exact-zero
+    similarities are dropped as nonzero() drops them.  feat: [I, F] on the GPU.  Returns the
+    graph with edata[weight_key] set."""
     if not feat.is_cuda:
         from . import _ffi
         raise _ffi.RkError(_ffi.RK_ERR_NODEV, "build_item_graph: features must be on the GPU")
@@ -146,17 +146,14 @@ def build_item_graph(feat: torch.Tensor, k: int, weight_key: str, chunk_rows: in
     feat = feat.float()
     nf = feat / torch.sqrt(torch.sum(feat ** 2, dim=1, keepdim=True))
     n = nf.shape[0]
-    src_parts, dst_parts, w_parts = [], [], []
-    for b in range(0, n, chunk_rows):
-        score = nf[b:b + chunk_rows] @ nf.T
-        vals, ids = ops.rows_topk(score, k)
-        inv = 1.0 / (vals.sum(dim=1, keepdim=True) + 1e-8)
-        w = inv * vals
-        order = torch.argsort(ids, dim=1)                  # nonzero() order: ascending column
-        ids, w = torch.gather(ids, 1, order), torch.gather(w, 1, order)
-        rows = torch.arange(b, b + ids.shape[0], device=feat.device, dtype=torch.int32).unsqueeze(1).expand_as(ids)
-        keep = w != 0
-        src_parts.append(ids[keep]), dst_parts.append(rows[keep]), w_parts.append(w[keep])
+    vals, ids = ops.score_topk_wide(nf, nf, k)
+    inv = 1.0 / (vals.sum(dim=1, keepdim=True) + 1e-8)
+    w = inv * vals
+    order = torch.argsort(ids, dim=1)                  # nonzero() order: ascending column
+    ids, w = torch.gather(ids, 1, order), torch.gather(w, 1, order)
+    rows = torch.arange(n, device=feat.device, dtype=torch.int32).unsqueeze(1).expand_as(ids)
+    keep = w != 0
+    src_parts, dst_parts, w_parts = [ids[keep]], [rows[keep]], [w[keep]]
     src = torch.cat(src_parts).cpu().numpy().astype(np.int32)
     dst = torch.cat(dst_parts).cpu().numpy().astype(np.int32)
     w = torch.cat(w_parts).float()
@@ -164,3 +161,36 @@ def build_item_graph(feat: torch.Tensor, k: int, weight_key: str, chunk_rows: in
     g.to(feat.device)
     g.edata[weight_key] = w
     return g
+
+
+class SGrecGraphOps:
+    """The graph half of the reference's SGrec `Graph` module (model/sgrec/graph.py:88-135) on the
+    device graph: build_graph, build_item_g and norm_adj / creat_graph_weight with the reference's
+    names, argument meaning and attribute names (num_users, num_items, num_nodes, device,
+    weight_cache, g).  The reference's module keeps its torch layers (feature MLPs, transformer)
+    and takes these three methods from here, with II_GCN / IU_GCN above as its propagation layers;
+    `dgl` is then no longer needed by that model."""
+
+    def build_graph(self, interactions) -> DeviceGraph:
+        """graph.py:88-98: edges u -> i+U, then i+U -> u, then one self loop per node, in that order."""
+        self.num_inter = len(interactions)
+        inter = np.asarray(interactions)
+        users = inter[:, 0].astype(np.int64)
+        items = inter[:, 1].astype(np.int64) + self.num_users
+        loops = np.arange(self.num_nodes, dtype=np.int64)
+        src = np.concatenate([users, items, loops]).astype(np.int32)
+        dst = np.concatenate([items, users, loops]).astype(np.int32)
+        self.g = DeviceGraph(src, dst, np.ones(src.shape[0], np.float32), self.num_nodes).to(self.device)
+        return self.g
+
+    def build_item_g(self, feat, k) -> DeviceGraph:
+        """graph.py:100-118."""
+        return build_item_graph(feat.to(self.device), k, self.weight_cache)
+
+    def creat_graph_weight(self):
+        self.norm_adj()
+
+    @torch.no_grad()
+    def norm_adj(self):
+        """graph.py:123-135: w_e = in_deg[src]^-0.5 * in_deg[dst]^-0.5."""
+        self.g.edata[self.weight_cache] = ops.deg_normalize(self.g.fwd)

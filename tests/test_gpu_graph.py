@@ -83,6 +83,39 @@ def test_spmm_forward_backward_vs_oracle(D, hub):
         assert gc.graph.fwd.n_long >= 1 and gc.graph.bwd.n_long >= 1
 
 
+def test_spmm_repeated_launches_on_one_operand_with_changing_inputs():
+    """Rows cut into several chunks hand their partial sums from workgroup to workgroup inside
+    the launch, through a buffer and counters that live with the operand.  Launch after launch
+    on the SAME operand with DIFFERENT inputs (each launch first reads the partial buffer's
+    old contents into the caches through plain loads) must give that launch's result: the hub
+    rows against float64, the whole output bit for bit against a second operand object that has
+    never been used before."""
+    U, I, E, hub = 500, 300, 4000, 9000
+    users, items, ratings = random_graph(U, I, E, 77, hub)
+    gc = build(users, items, ratings, U, I)
+    gc.creat_feature_weight(None)
+    gc.graph.refresh_values("weight")
+    fwd = gc.graph.fwd
+    assert fwd.n_multi >= 1
+    src, dst, w = graph_oracle.build_coo_vectorized(users, items, ratings, U, I, True)
+    wn, _ = graph_oracle.normalize(src, dst, w, U + I)
+    rng = np.random.default_rng(5)
+    for it in range(12):
+        h = (rng.standard_normal((U + I, 64)) * (it + 1)).astype(np.float32)
+        ht = torch.from_numpy(h).to(DEV)
+        part, _ = fwd._partial.get(64, (None, None))
+        if part is not None:
+            float(part.sum())                      # plain loads of every partial line, old contents
+        out = ops.spmm_raw(fwd, ht).cpu().numpy()
+        ref = graph_oracle.spmm_f64(src, dst, wn, h)
+        assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max(), it
+        fresh = ops.CsrMatrix(gc.graph.csr_host[0], gc.graph.csr_host[1], gc.graph.csr_host[2], DEV)
+        fresh.set_values_from_coo(gc.graph.edata["weight"])
+        np.testing.assert_array_equal(out, ops.spmm_raw(fresh, ht).cpu().numpy())
+    # the counters are back at zero after every launch
+    assert int(fwd._partial[64][1].abs().sum()) == 0
+
+
 def test_aggrate_and_agg_func_vs_oracle():
     U, I, E, D = 200, 150, 2500, 64
     users, items, ratings = random_graph(U, I, E, 5, 400)

@@ -107,7 +107,7 @@ def test_item_knn_graph_vs_dense_oracle():
     rng = np.random.default_rng(9)
     feat = rng.standard_normal((700, 384)).astype(np.float32)
     from recommend_amd.propagation import build_item_graph
-    g = build_item_graph(torch.from_numpy(feat).to(DEV), 10, "ii_weight", chunk_rows=256)
+    g = build_item_graph(torch.from_numpy(feat).to(DEV), 10, "ii_weight")
     src, dst, w = graph_oracle.build_item_graph(feat, 10)
     np.testing.assert_array_equal(g.src, src)
     np.testing.assert_array_equal(g.dst, dst)
@@ -117,3 +117,77 @@ def test_item_knn_graph_vs_dense_oracle():
     x = torch.randn(700, 64, device=DEV)
     out = II_GCN(2, 0.1, 0.9, 0.0, 0.0, 0.0, "ii_weight").eval()(x, g)
     _close(out.cpu().numpy(), graph_oracle.ii_gcn_forward(src, dst, w.astype(np.float32), x.cpu().numpy(), 2, 0.1, 0.9))
+
+
+@pytest.mark.parametrize("n_a,n_b,F,K", [(700, 700, 384, 10), (300, 1000, 4096, 20), (65, 33, 64, 32),
+                                         (1, 129, 128, 4), (1000, 257, 200, 5), (513, 4100, 192, 12)])
+def test_score_topk_wide_vs_float64(n_a, n_b, F, K):
+    """rk_score_topk_wide_f32 (the similarity + top-K of the item kNN graph, feature width as a loop
+    inside the kernel) against a float64 score matrix: values to 1e-5 of |a||b|, ids equal wherever
+    the float64 scores around the list are further apart than that."""
+    from recommend_amd import ops
+    rng = np.random.default_rng(n_a + n_b + F)
+    A = rng.standard_normal((n_a, F)).astype(np.float32)
+    B = rng.standard_normal((n_b, F)).astype(np.float32)
+    vals, ids = ops.score_topk_wide(torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV), K)
+    vals, ids = vals.cpu().numpy(), ids.cpu().numpy().astype(np.int64)
+    S = A.astype(np.float64) @ B.astype(np.float64).T
+    scale = np.linalg.norm(A, axis=1, keepdims=True) * np.linalg.norm(B, axis=1).max()
+    order = np.argsort(-S, axis=1, kind="stable")
+    want_ids = order[:, :K]
+    want = np.take_along_axis(S, want_ids, 1)
+    assert (ids >= 0).all() and (ids < n_b).all()
+    got64 = np.take_along_axis(S, ids, 1)
+    assert (np.abs(vals - got64) <= 1e-5 * scale).all()
+    assert (np.diff(vals, axis=1) <= 0).all()
+    assert (np.abs(got64 - want) <= 2e-5 * scale).all()           # the same scores, place by place
+    # a place is clear when its float64 score is further than the tolerance from both neighbours
+    # in the float64 ranking (the (K+1)-th included)
+    ext = np.take_along_axis(S, order[:, :min(K + 1, n_b)], 1)
+    gap = np.abs(np.diff(ext, axis=1)) > 4e-5 * scale
+    gap = np.concatenate([np.ones((n_a, 1), bool), gap, np.ones((n_a, 1), bool)], axis=1)
+    clear = gap[:, :K] & gap[:, 1:K + 1]
+    assert clear.mean() > 0.5
+    np.testing.assert_array_equal(ids[clear], want_ids[clear])
+
+
+def test_score_topk_wide_ties_go_to_the_lower_id():
+    """Small integer features make every product and sum exact in fp32, so equal scores are equal
+    bits: the ranking must be numpy's stable descending order, duplicated rows included."""
+    from recommend_amd import ops
+    rng = np.random.default_rng(4)
+    X = rng.integers(-3, 4, (600, 128)).astype(np.float32)
+    X[100:200] = X[300:400]                       # duplicated rows: whole score columns tie
+    vals, ids = ops.score_topk_wide(torch.from_numpy(X).to(DEV), torch.from_numpy(X).to(DEV), 15)
+    S = X.astype(np.int64) @ X.astype(np.int64).T
+    want = np.argsort(-S, axis=1, kind="stable")[:, :15]
+    np.testing.assert_array_equal(ids.cpu().numpy(), want)
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(S, want, 1).astype(np.float32))
+    from recommend_amd import _ffi
+    with pytest.raises(_ffi.RkError):
+        ops.score_topk_wide(torch.from_numpy(X).to(DEV), torch.from_numpy(X).to(DEV), 33)
+
+
+def test_sgrec_graph_methods_vs_oracle():
+    """SGrecGraphOps (build_graph / norm_adj of model/sgrec/graph.py:88-135) feeding IU_GCN: edge order,
+    degree normalisation and k hops against the oracle."""
+    from recommend_amd.propagation import SGrecGraphOps
+
+    class G(SGrecGraphOps):
+        num_users, num_items, num_nodes, device, weight_cache = 120, 80, 200, DEV, "weight"
+
+    rng = np.random.default_rng(2)
+    inter = [(int(u), int(i), 1.0) for u, i in zip(rng.integers(0, 120, 900), rng.integers(0, 80, 900))]
+    gm = G()
+    g = gm.build_graph(inter)
+    gm.creat_graph_weight()
+    u = np.array([t[0] for t in inter]); it = np.array([t[1] for t in inter]) + 120
+    loops = np.arange(200)
+    src = np.concatenate([u, it, loops]); dst = np.concatenate([it, u, loops])
+    np.testing.assert_array_equal(g.src, src)
+    np.testing.assert_array_equal(g.dst, dst)
+    w = graph_oracle.deg_normalize(src, dst, 200)
+    np.testing.assert_allclose(g.edata["weight"].cpu().numpy(), w, rtol=1e-6)
+    x = torch.randn(200, 64, device=DEV)
+    out = IU_GCN(0.0, 0.0, 0.0, "weight").eval()(x, g, 2)
+    _close(out.cpu().numpy(), graph_oracle.iu_gcn_forward(src, dst, w.astype(np.float32), x.cpu().numpy(), 2))

@@ -412,6 +412,10 @@ int main(int argc, char **argv) {
   plan.chunk_row = d_crow, plan.chunk_begin = d_cbeg, plan.chunk_end = d_cend, plan.chunk_slot = d_cslot;
   plan.n_multi = nm, plan.multi_rows = d_mrows, plan.multi_slot_ptr = d_mptr, plan.n_slots = ns;
   plan.partial = d_partial;
+  int32_t *d_arrive;
+  CK(hipMalloc(&d_arrive, std::max(nm, 1) * 4));
+  CK(hipMemset(d_arrive, 0, std::max(nm, 1) * 4));
+  plan.arrive = d_arrive;
 
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
