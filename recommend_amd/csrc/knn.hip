@@ -22,6 +22,7 @@ namespace {
 constexpr int GT = 4;          // 32-row B tiles per group
 constexpr int GI = GT * TI;    // B rows per group
 constexpr int CH = 64;         // floats per chunk of the width
+typedef float floatx4 __attribute__((ext_vector_type(4)));   // (arrays of HIP's float4 struct end up in scratch)
 constexpr int LDB = CH + 4;    // LDS row pitch in floats (shifts consecutive rows by four banks)
 
 template <int KPAD>
@@ -53,19 +54,25 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
 
   // registers of the step in flight: this thread's 8 float4 of the next B chunk (row e / 16,
   // float4 e % 16 for e = tid + 256 i) and the next A chunk of the two user columns of this lane
-  float4 bpre[8];
+  floatx4 bpre[8];
   float ua[32], ub[32], ua_n[32], ub_n[32];
-  auto fetch = [&](int32_t g, int32_t c) {
+  // where this thread's 8 float4 of a B chunk come from: fixed per group, advanced by the chunk
+  const float *bp[8];
+  auto set_group = [&](int32_t g) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
       const int64_t row = min(g * GI + e / 16, n_b - 1);   // rows past the end repeat the last; discarded later
-      bpre[i] = *reinterpret_cast<const float4 *>(B + row * F + c * CH + (e % 16) * 4);
+      bp[i] = B + row * F + (e % 16) * 4;
     }
+  };
+  auto fetch = [&](int32_t c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bpre[i] = *reinterpret_cast<const floatx4 *>(bp[i] + c * CH);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float4 va = *reinterpret_cast<const float4 *>(pa + c * CH + 4 * q);
-      const float4 vb = *reinterpret_cast<const float4 *>(pb + c * CH + 4 * q);
+      const floatx4 va = *reinterpret_cast<const floatx4 *>(pa + c * CH + 4 * q);
+      const floatx4 vb = *reinterpret_cast<const floatx4 *>(pb + c * CH + 4 * q);
       ua_n[4 * q + 0] = va.x; ua_n[4 * q + 1] = va.y; ua_n[4 * q + 2] = va.z; ua_n[4 * q + 3] = va.w;
       ub_n[4 * q + 0] = vb.x; ub_n[4 * q + 1] = vb.y; ub_n[4 * q + 2] = vb.z; ub_n[4 * q + 3] = vb.w;
     }
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int e = tid + 256 * i;
-      *reinterpret_cast<float4 *>(&Bs[buf][e / 16][(e % 16) * 4]) = bpre[i];
+      *reinterpret_cast<floatx4 *>(&Bs[buf][e / 16][(e % 16) * 4]) = bpre[i];
     }
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
@@ -83,87 +90,87 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
     }
   };
 
-  floatx16 acc_a[GT], acc_b[GT];
-#pragma unroll
-  for (int j = 0; j < GT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc_a[j][r] = 0.0f;
-      acc_b[j][r] = 0.0f;
-    }
-
   if (steps > 0) {
-    fetch(g_lo, 0);
+    set_group(g_lo);
+    fetch(0);
     stage(0);
   }
   __syncthreads();
-  int32_t g = g_lo, c = 0;
-  for (int64_t s = 0; s < steps; ++s) {
-    const int buf = (int)(s & 1);
-    int32_t gn = g, cn = c + 1;
-    if (cn == n_chunks) {
-      cn = 0;
-      ++gn;
-    }
-    const bool more = s + 1 < steps;     // uniform over the workgroup
-    if (more) fetch(gn, cn);
+  int64_t s = 0;
+  for (int32_t g = g_lo; g < g_hi; ++g) {
+    // (the accumulators are set up per group and carried only through the MFMAs of the chunk
+    // loop: a zero that travels around the loop as well makes the compiler move all of them
+    // between the two register files every step)
+    floatx16 acc_a[GT], acc_b[GT];
 #pragma unroll
-    for (int j = 0; j < GT; ++j) {
-      float bf[32];
+    for (int j = 0; j < GT; ++j)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(&Bs[buf][TI * j + col][32 * half + 4 * q]);
-        bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+      for (int r = 0; r < 16; ++r) {
+        acc_a[j][r] = 0.0f;
+        acc_b[j][r] = 0.0f;
       }
-      // B rows on the MFMA rows, users on the columns: chain k = 0, 32, 1, 33, ... of this chunk
-#pragma unroll
-      for (int m = 0; m < 32; ++m) {
-        acc_a[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[m], ua[m], acc_a[j], 0, 0, 0);
-        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[m], ub[m], acc_b[j], 0, 0, 0);
+    for (int32_t c = 0; c < n_chunks; ++c, ++s) {
+      const int buf = (int)(s & 1);
+      const bool more = s + 1 < steps;     // uniform over the workgroup
+      if (more) {
+        if (c + 1 == n_chunks) set_group(g + 1);
+        fetch(c + 1 < n_chunks ? c + 1 : 0);
       }
-    }
-    if (c == n_chunks - 1) {
-      // the group has seen the whole width: offer its 128 scores per user, ascending ids
+      // the fragment of tile j+1 is read from LDS while the MFMAs of tile j run
+      floatx4 bf[2][8];
+      auto read_frag = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          bf[j & 1][q] = *reinterpret_cast<const floatx4 *>(&Bs[buf][TI * j + col][32 * half + 4 * q]);
+      };
+      read_frag(0);
 #pragma unroll
       for (int j = 0; j < GT; ++j) {
-        // lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in
-        // acc_b; after the swap lane l holds, for user ubase+l, rows (r&3)+8*(r>>2) in lo[r] and
-        // rows 4+(r&3)+8*(r>>2) in hi[r].  The s_nop pair covers the wait states between the last
-        // MFMA pass and a vector read of its result, which the compiler does not insert in front
-        // of inline assembly.
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a[j]), "+v"(acc_b[j]));
-        float lo[16], hi[16];
+        if (j + 1 < GT) read_frag(j + 1);
+        // B rows on the MFMA rows, users on the columns: chain k = 0, 32, 1, 33, ... of this chunk
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          lo[r] = acc_a[j][r];
-          hi[r] = acc_b[j][r];
-          acc_a[j][r] = 0.0f;
-          acc_b[j][r] = 0.0f;
+        for (int m = 0; m < 32; ++m) {
+          acc_a[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j & 1][m / 4][m % 4], ua[m], acc_a[j], 0, 0, 0);
+          acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j & 1][m / 4][m % 4], ub[m], acc_b[j], 0, 0, 0);
         }
+      }
+      if (more) stage(buf ^ 1);
+      __syncthreads();
+    }
+    // the group has seen the whole width: offer its 128 scores per user, ascending ids
 #pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
-        const int32_t item0 = (g * GT + j) * TI;
-        if (item0 < n_b) {                 // uniform
+    for (int j = 0; j < GT; ++j) {
+      // lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in
+      // acc_b; after the swap lane l holds, for user ubase+l, rows (r&3)+8*(r>>2) in lo[r] and
+      // rows 4+(r&3)+8*(r>>2) in hi[r].  The s_nop pair covers the wait states between the last
+      // MFMA pass and a vector read of its result, which the compiler does not insert in front
+      // of inline assembly.
+      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc_a[j]), "+a"(acc_b[j]));
+      float lo[16], hi[16];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+      for (int r = 0; r < 16; ++r) {
+        lo[r] = acc_a[j][r];
+        hi[r] = acc_b[j][r];
+      }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const int32_t id = item0 + 8 * q + i;
-              float v = i < 4 ? lo[4 * q + i] : hi[4 * q + i - 4];
-              if (id >= n_b) v = -INFINITY;
-              if (__any(v > thr)) {
-                list.insert(v, id);
-                thr = list.s[KPAD - 1];
-              }
+      for (int r = 0; r < 16; ++r) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
+      const int32_t item0 = (g * GT + j) * TI;
+      if (item0 < n_b) {                 // uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int32_t id = item0 + 8 * q + i;
+            float v = i < 4 ? lo[4 * q + i] : hi[4 * q + i - 4];
+            if (id >= n_b) v = -INFINITY;
+            if (__any(v > thr)) {
+              list.insert(v, id);
+              thr = list.s[KPAD - 1];
             }
           }
         }
       }
     }
-    if (more) stage(buf ^ 1);
-    __syncthreads();
-    g = gn;
-    c = cn;
   }
 
   if (user < n_a) {

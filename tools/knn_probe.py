@@ -7,7 +7,7 @@ from recommend_amd import ops
 
 I, K = int(os.environ.get("KNN_ITEMS", 63001)), 10
 for F in (384, 4096):
-    x = torch.nn.functional.normalize(torch.randn(I, F, device="cuda"))
+    x = torch.nn.functional.normalize(torch.randn(I, F, device="cuda", generator=torch.Generator("cuda").manual_seed(F)))
     ops.score_topk_wide(x[:512], x, K)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -21,4 +21,5 @@ for F in (384, 4096):
         v2, i2 = ops.rows_topk(s, K)
     torch.cuda.synchronize()
     print(f"        library GEMM + rows_topk in blocks of 8192 rows: {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
-    print("        last block ids equal:", bool(torch.equal(i[b:], i2)), flush=True)
+    # (random rows: a few near-ties may rank differently under the library's accumulation order)
+    print("        rows of the last block whose ids differ:", int((i[b:] != i2).any(1).sum()), "of", i2.shape[0], flush=True)
