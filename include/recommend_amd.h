@@ -307,7 +307,9 @@ int rk_bpr_fwd_f32(const float *U, const float *I, int32_t D,
                    const int32_t *pos_items, int32_t n_items, float *x_out,
                    float *loss_out, void *ws, size_t ws_bytes, void *stream);
 /* Gradient of the loss above w.r.t. U and I rows, scaled by *gout (device
- * scalar), accumulated with float atomics into dU/dI (caller zero-fills). */
+ * scalar), added into dU/dI (caller zero-fills).  Up to 32768 contributions
+ * (B * (1 + R)) every row is summed by one lane group in sample order: the result
+ * is bit-reproducible.  Larger batches accumulate with float atomics. */
 int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
                    const int64_t *users, const int64_t *pos, const int64_t *neg,
                    int64_t B, int32_t R, const float *mask, const float *x,

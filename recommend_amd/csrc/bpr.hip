@@ -204,6 +204,109 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
   atomic_axpy(dU + u * D, pi, gsum, d4, sub);
 }
 
+// ---- bit-reproducible backward ---------------------------------------------------------------
+// Every row of dU / dI is written by ONE lane group, which adds the row's contributions in index
+// order in registers: contribution c of the user side is sample c (key users[c]); of the item side
+// c < B is the positive of sample c (key pos[c]), c >= B the negative c - B (key neg[c - B]).  The
+// group of contribution c scans all keys 16 at a time; if an earlier contribution has its key it
+// leaves (that one owns the row), otherwise it accumulates every match as the scan passes it.  No
+// atomics, no sorting, no scratch; n^2 / 16 compare steps of a lane group for n contributions
+// (n = 512 at the Elec preset: 32 steps per group), which is why rk_rank_loss_bwd_f32 switches to
+// the atomic kernel above kDetMaxContrib contributions.
+constexpr int64_t kDetMaxContrib = 32768;
+constexpr int kMaxQ = 4;   // float4 per lane and pass: rows up to 256 floats in one pass, wider rows in several
+
+// d loss / d x of negative r of one sample (x_row / mask_row: the sample's R saved values), as in
+// bpr_bwd_kernel
+__device__ __forceinline__ float bwd_coef(const float *__restrict__ x_row, const float *__restrict__ mask_row,
+                                          int32_t r, float scale, int mode) {
+  const float xv = x_row[r];
+  const float m = mask_row ? mask_row[r] : 1.0f;
+  return mode == kModeSoftmaxCE ? -scale * expf(xv) : -scale * m / (1.0f + expf(xv));
+}
+
+template <bool ITEMS>
+__global__ __launch_bounds__(256) void bpr_bwd_det_kernel(
+    const float *__restrict__ U, const float *__restrict__ I, int32_t D,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+    const int64_t *__restrict__ neg, int64_t B, int32_t R,
+    const float *__restrict__ mask, const float *__restrict__ x,
+    const float *__restrict__ loss_out, const float *__restrict__ gout, int mode,
+    float *__restrict__ dst) {
+  const int sub = threadIdx.x % GL;
+  const int64_t n = ITEMS ? B * (1 + R) : B;
+  const int64_t c = (int64_t)blockIdx.x * SPB + threadIdx.x / GL;
+  if (c >= n) return;                       // whole lane groups leave; nothing below synchronises wider
+  auto key = [&](int64_t i) -> int64_t { return !ITEMS ? users[i] : (i < B ? pos[i] : neg[i - B]); };
+  const int64_t my = key(c);
+  const int d4 = D / 4;
+  const float scale = gout[0] / loss_out[1];
+  const int gshift = (threadIdx.x % rk::kWave) / GL * GL;   // this group's bits in a wavefront ballot
+
+  for (int q0 = 0; q0 < d4; q0 += GL * kMaxQ) {
+    float4 acc[kMaxQ];
+#pragma unroll
+    for (int t = 0; t < kMaxQ; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto axpy = [&](const float *row, float a) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+      for (int t = 0; t < kMaxQ; ++t) {
+        const int q = q0 + t * GL + sub;
+        if (q < d4) {
+          const float4 v = r4[q];
+          acc[t].x = fmaf(a, v.x, acc[t].x);
+          acc[t].y = fmaf(a, v.y, acc[t].y);
+          acc[t].z = fmaf(a, v.z, acc[t].z);
+          acc[t].w = fmaf(a, v.w, acc[t].w);
+        }
+      }
+    };
+    for (int64_t c0 = 0; c0 < n; c0 += GL) {
+      const int64_t cc = c0 + sub;
+      const bool hit = cc < n && key(cc) == my;
+      uint32_t bits = (uint32_t)((__ballot(hit) >> gshift) & 0xFFFFu);
+      if (c0 < c) {
+        const int64_t below = c - c0;       // indices c0 .. c0 + below - 1 come before c
+        if (bits & (below >= GL ? 0xFFFFu : ((1u << below) - 1u))) return;   // an earlier contribution owns the row
+        if (below < GL) bits &= ~((1u << below) - 1u);
+      }
+      while (bits) {
+        const int b = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const int64_t ci = c0 + b;
+        if (!ITEMS) {
+          // d/dU[u] of sample ci: sum_r (-g_r) * I[neg_r] + (sum_r g_r) * I[pos]
+          float gsum = 0.0f;
+          for (int32_t r = 0; r < R; ++r) {
+            const float g = bwd_coef(x + ci * R, mask ? mask + ci * R : nullptr, r, scale, mode);
+            axpy(I + neg[ci * R + r] * D, -g);
+            gsum += g;
+          }
+          axpy(I + pos[ci] * D, gsum);
+        } else if (ci < B) {
+          float gsum = 0.0f;
+          for (int32_t r = 0; r < R; ++r) gsum += bwd_coef(x + ci * R, mask ? mask + ci * R : nullptr, r, scale, mode);
+          axpy(U + users[ci] * D, gsum);
+        } else {
+          const int64_t sr = ci - B, smp = sr / R;
+          const float g = bwd_coef(x + smp * R, mask ? mask + smp * R : nullptr, (int32_t)(sr - smp * R), scale, mode);
+          axpy(U + users[smp] * D, -g);
+        }
+      }
+    }
+    float4 *out4 = reinterpret_cast<float4 *>(dst + my * D);
+#pragma unroll
+    for (int t = 0; t < kMaxQ; ++t) {
+      const int q = q0 + t * GL + sub;
+      if (q < d4) {
+        float4 o = out4[q];
+        o.x += acc[t].x; o.y += acc[t].y; o.z += acc[t].z; o.w += acc[t].w;
+        out4[q] = o;
+      }
+    }
+  }
+}
+
 // score-level form of the same loss (bpr_loss called on precomputed scores)
 __global__ __launch_bounds__(256) void bpr_scores_fwd_kernel(
     const float *__restrict__ pos, const float *__restrict__ neg, int64_t B, int32_t R,
@@ -386,9 +489,21 @@ int rk_rank_loss_bwd_f32(const float *U, const float *I, int32_t D,
   RK_CHECK_ARG(B > 0 && R > 0, "empty batch");
   RK_CHECK_ARG(U && I && users && pos && neg && x && loss_out && gout && dU && dI, "null pointer");
   RK_CHECK_ARG(D > 0 && D % 4 == 0, "embedding width must be a multiple of 4");
-  bpr_bwd_kernel<<<(int32_t)rk::ceil_div(B, SPB), 256, 0, (hipStream_t)stream>>>(
-      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dU, dI);
-  RK_CHECK_LAUNCH("bpr_bwd_kernel");
+  hipStream_t st = (hipStream_t)stream;
+  if (B * (1 + (int64_t)R) > kDetMaxContrib) {
+    // very large batches: float atomics (sums of three or more contributions to one row may then
+    // differ in the last bits from run to run)
+    bpr_bwd_kernel<<<(int32_t)rk::ceil_div(B, SPB), 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask, x, loss_out,
+                                                                   gout, mode, dU, dI);
+    RK_CHECK_LAUNCH("bpr_bwd_kernel");
+    return RK_OK;
+  }
+  bpr_bwd_det_kernel<false><<<(int32_t)rk::ceil_div(B, SPB), 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask, x,
+                                                                          loss_out, gout, mode, dU);
+  RK_CHECK_LAUNCH("bpr_bwd_det_kernel<users>");
+  bpr_bwd_det_kernel<true><<<(int32_t)rk::ceil_div(B * (1 + (int64_t)R), SPB), 256, 0, st>>>(
+      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dI);
+  RK_CHECK_LAUNCH("bpr_bwd_det_kernel<items>");
   return RK_OK;
 }
 

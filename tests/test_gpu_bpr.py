@@ -119,7 +119,7 @@ def test_in_kernel_negative_lookup_is_bit_exact(R):
                                      "neg_items": torch.from_numpy(neg)})
     assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
     loss2.backward()
-    torch.testing.assert_close(ue.grad, g1, rtol=1e-4, atol=1e-6)     # atomics: order differs
+    torch.testing.assert_close(ue.grad, g1, rtol=1e-4, atol=1e-6)
 
 
 def test_forward_is_deterministic():
@@ -131,6 +131,32 @@ def test_forward_is_deterministic():
     neg = torch.randint(0, I, (B, 2), generator=g).to(DEV)
     vals = {float(ops.bpr_gather_dot(ue, ie, users, pos, neg)) for _ in range(5)}
     assert len(vals) == 1
+
+
+@pytest.mark.parametrize("B,R,D,U,I", [(4096, 2, 64, 50, 40), (300, 3, 320, 7, 9), (1, 1, 16, 3, 3), (20000, 1, 64, 100, 100)])
+def test_backward_with_heavy_collisions_vs_float64_and_bit_reproducible(B, R, D, U, I):
+    """Few users and items, so every gradient row is the sum of many samples' contributions.
+    Against a float64 restatement of the gradient (1e-5 of scale); up to 32768 contributions the
+    rows are summed by one lane group in sample order, so repeated calls give identical bits (the
+    last case is above that limit and takes the atomic kernel: values only)."""
+    g = torch.Generator().manual_seed(B + D)
+    ue, ie = torch.randn(U, D, generator=g), torch.randn(I, D, generator=g)
+    users = torch.randint(0, U, (B,), generator=g)
+    pos = torch.randint(0, I, (B,), generator=g)
+    neg = torch.randint(0, I, (B, R), generator=g)
+    grads = []
+    for _ in range(3):
+        ud, idv = ue.to(DEV).requires_grad_(True), ie.to(DEV).requires_grad_(True)
+        ops.bpr_gather_dot(ud, idv, users.to(DEV), pos.to(DEV), neg.to(DEV)).backward()
+        grads.append((ud.grad.clone(), idv.grad.clone()))
+    u6, i6 = ue.double().requires_grad_(True), ie.double().requires_grad_(True)
+    x = (u6[users] * i6[pos]).sum(1, keepdim=True) - (u6[users].unsqueeze(1) * i6[neg]).sum(2)
+    (-torch.nn.functional.logsigmoid(x)).mean().backward()
+    assert relerr(grads[0][0].cpu().double().numpy(), u6.grad.numpy()) <= 1e-5
+    assert relerr(grads[0][1].cpu().double().numpy(), i6.grad.numpy()) <= 1e-5
+    if B * (1 + R) <= 32768:
+        for gu, gi in grads[1:]:
+            assert torch.equal(gu, grads[0][0]) and torch.equal(gi, grads[0][1])
 
 
 @pytest.mark.parametrize("name", CASES)

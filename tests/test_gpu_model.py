@@ -146,3 +146,39 @@ def test_graphed_train_step_matches_eager_steps():
         assert int(st3.step_counter) == c0 + 2
     finally:
         ops.set_dropout_step_tensor(None)
+
+
+def test_training_is_bit_reproducible_run_to_run():
+    """No kernel of the training step adds floats in an order that depends on timing (hop partial
+    rows, layer and projection reductions, loss and its backward, clip norm): two runs from the same
+    seeds -- dropout on -- end with identical parameter bits."""
+    import itertools
+    from recommend_amd import ops
+    from recommend_amd.optim import FusedClipAdam
+    U, I, D = 400, 250, 64
+
+    def run():
+        ops._seed_counter = itertools.count(1)
+        model, d, feats, (tu, ti, tr) = build_model(U, I, D, 6000, 0.3, seed=11)
+        # one very active user and one very popular item: rows cut into chunks, gradient rows with many terms
+        p, it = build_user_csr(d.users, d.items, U)
+        sampler = NegativeSampler(p, it, I, seed=3)
+        dp, di = sampler.device_csr(DEV)
+        loader = TrainBatchLoader(tu, ti, tr, 512, sampler, shuffle=False, device=DEV, resolve_on_host=False)
+        opt = FusedClipAdam(model.parameters(), lr=0.01, max_grad_norm=1.0)
+        model.train()
+        losses = []
+        for batch in itertools.islice(loader, 5):
+            batch["pos_ptr"], batch["pos_items"] = dp, di
+            opt.zero_grad()
+            loss = gather_dot_bpr_loss(model(batch), batch)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return losses, [q.detach().clone() for q in model.parameters()]
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert l1 == l2
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)
