@@ -72,14 +72,13 @@ __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, in
 // of lists; the indirection through user_list applies if it is given).
 __device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, const int32_t *user_list,
                                           const int32_t *user_count, int32_t gate_cap, int32_t rows_per_user,
-                                          int32_t &row_in, int32_t &row_out) {
-  row_in = blockIdx.x * 4 + threadIdx.x / kWave;
+                                          int32_t row_in, int32_t &row_out) {
   if (user_count != nullptr) {
     const int32_t cnt = user_count[0];
     if (rows_per_user > 0 ? cnt > gate_cap : cnt <= gate_cap) return false;
     if (rows_per_user > 0) n_rows = min(n_rows, cnt * rows_per_user);
   }
-  if (row_in >= n_rows) return false;  // wave-uniform; no block barrier in the callers
+  if (row_in >= n_rows) return false;  // uniform over the lanes that share a row
   row_out = user_list != nullptr ? user_list[row_in] : row_in;
   return skip == nullptr || skip[row_out] == 0;   // flagged rows of out are already final
 }
@@ -88,30 +87,49 @@ __device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, c
 // the launch (n entries per row, not MERGE_MAX): a merge lives on the number of rows in flight.
 extern __shared__ float merge_lds[];
 
+// RPW rows per workgroup: 4 = one wavefront per row (many rows), 1 = the whole workgroup on one
+// row (the few rows of the compacted launch, where one wavefront's chain of dependent LDS reads is
+// what the launch takes).  Workgroups walk the rows with a grid stride, so a launch that is gated
+// off on the device, or has few rows, does not pay for one workgroup per four rows of the table.
+template <int RPW>
+__device__ __forceinline__ void merge_sync() {
+  if constexpr (RPW == 1) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS accesses are done
+  }
+}
+
+template <int RPW>
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t n, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
     int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  float *cs_w = merge_lds + (size_t)wave * 2 * n;
+  constexpr int LANES = 256 / RPW;
+  const int sub_row = threadIdx.x / LANES, lane = threadIdx.x % LANES;
+  float *cs_w = merge_lds + (size_t)sub_row * 2 * n;
   int32_t *ci_w = reinterpret_cast<int32_t *>(cs_w + n);
-  int32_t pos, user;
-  if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
-  for (int c = lane; c < n; c += kWave) {
-    cs_w[c] = scores[(int64_t)pos * n + c];
-    ci_w[c] = ids[(int64_t)pos * n + c];
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
-  for (int c = lane; c < n; c += kWave) {
-    const float sc = cs_w[c];
-    const int32_t ic = ci_w[c];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += beats(cs_w[j], ci_w[j], j, sc, ic, c) ? 1 : 0;
-    if (rank < K) {
-      out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
-      out_id[(int64_t)user * K + rank] = ic;
+  for (int64_t rb = blockIdx.x; rb * RPW < n_users; rb += gridDim.x) {
+    const int32_t pos = (int32_t)(rb * RPW) + sub_row;
+    int32_t user;
+    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) continue;
+    merge_sync<RPW>();                 // the row before is done with the buffer
+    for (int c = lane; c < n; c += LANES) {
+      cs_w[c] = scores[(int64_t)pos * n + c];
+      ci_w[c] = ids[(int64_t)pos * n + c];
+    }
+    merge_sync<RPW>();
+    for (int c = lane; c < n; c += LANES) {
+      const float sc = cs_w[c];
+      const int32_t ic = ci_w[c];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += beats(cs_w[j], ci_w[j], j, sc, ic, c) ? 1 : 0;
+      if (rank < K) {
+        out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
+        out_id[(int64_t)user * K + rank] = ic;
+      }
     }
   }
 }
@@ -120,43 +138,48 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
 // asc), padding last -- as the lists of score_topk_kernel and of this kernel are.  An entry is
 // beaten by the entries in front of it in its own list and by a prefix of every other list, found
 // by bisection: P * log2(Kin) steps per entry instead of P * Kin.
+template <int RPW>
 __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t P, int32_t Kin, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
     int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  constexpr int LANES = 256 / RPW;
+  const int sub_row = threadIdx.x / LANES, lane = threadIdx.x % LANES;
   const int n = P * Kin;
-  float *cs_w = merge_lds + (size_t)wave * 2 * n;
+  float *cs_w = merge_lds + (size_t)sub_row * 2 * n;
   int32_t *ci_w = reinterpret_cast<int32_t *>(cs_w + n);
-  int32_t pos, user;
-  if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) return;
-  for (int c = lane; c < n; c += kWave) {
-    cs_w[c] = scores[(int64_t)pos * n + c];
-    ci_w[c] = ids[(int64_t)pos * n + c];
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done
-  for (int c = lane; c < n; c += kWave) {
-    const float sc = cs_w[c];
-    const int32_t ic = ci_w[c];
-    const int own = c / Kin;
-    int rank = c - own * Kin;
-    for (int q = 0; q < P; ++q) {
-      if (q == own) continue;
-      int lo = 0, hi = Kin;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1, j = q * Kin + mid;
-        if (beats(cs_w[j], ci_w[j], j, sc, ic, c))
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      rank += lo;
+  for (int64_t rb = blockIdx.x; rb * RPW < n_users; rb += gridDim.x) {
+    const int32_t pos = (int32_t)(rb * RPW) + sub_row;
+    int32_t user;
+    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) continue;
+    merge_sync<RPW>();                 // the row before is done with the buffer
+    for (int c = lane; c < n; c += LANES) {
+      cs_w[c] = scores[(int64_t)pos * n + c];
+      ci_w[c] = ids[(int64_t)pos * n + c];
     }
-    if (rank < K) {
-      out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
-      out_id[(int64_t)user * K + rank] = ic;
+    merge_sync<RPW>();
+    for (int c = lane; c < n; c += LANES) {
+      const float sc = cs_w[c];
+      const int32_t ic = ci_w[c];
+      const int own = c / Kin;
+      int rank = c - own * Kin;
+      for (int q = 0; q < P; ++q) {
+        if (q == own) continue;
+        int lo = 0, hi = Kin;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1, j = q * Kin + mid;
+          if (beats(cs_w[j], ci_w[j], j, sc, ic, c))
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < K) {
+        out_s[(int64_t)user * K + rank] = ic >= 0 ? sc : -INFINITY;
+        out_id[(int64_t)user * K + rank] = ic;
+      }
     }
   }
 }
@@ -182,17 +205,36 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
     const int32_t tb = tgt_ptr[u], te = tgt_ptr[u + 1];
     const int32_t n_pos = te - tb;
     uint32_t rel = 0;  // bit j: j-th ranked item is a target item
-    for (int j = 0; j < kmax; ++j) {
-      const int32_t it = topk_ids[(int64_t)u * id_stride + j];
-      int32_t lo = tb, hi = te;
-      while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (tgt_items[mid] < it)
-          lo = mid + 1;
-        else
-          hi = mid;
+    // The ranked ids go to registers with independent loads.  A user with a handful of target
+    // items compares each of them with all ranked ids (a bisection per ranked item is a chain of
+    // dependent loads four deep, kmax times over); the few users with long target lists bisect (a
+    // walk over thousands of targets is thousands of dependent loads in one lane: 2.5 ms at Elec).
+    int32_t ranked[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) ranked[j] = j < kmax ? topk_ids[(int64_t)u * id_stride + j] : -1;
+    if (n_pos <= 16) {
+      for (int32_t t = tb; t < te; ++t) {
+        const int32_t v = tgt_items[t];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rel |= (ranked[j] == v && v >= 0 ? 1u : 0u) << j;
       }
-      if (it >= 0 && lo < te && tgt_items[lo] == it) rel |= 1u << j;
+    } else {
+      // long target lists (sorted): a bisection per ranked item
+#pragma unroll 1
+      for (int j = 0; j < kmax; ++j) {
+        int32_t it = ranked[0];
+#pragma unroll
+        for (int q = 1; q < 32; ++q) it = q == j ? ranked[q] : it;   // (no indexed access: the ids stay in registers)
+        int32_t lo = tb, hi = te;
+        while (lo < hi) {
+          const int32_t mid = (lo + hi) >> 1;
+          if (tgt_items[mid] < it)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        if (it >= 0 && lo < te && tgt_items[lo] == it) rel |= 1u << j;
+      }
     }
     // evalue/metric.py:119-155, per user, fp32
     const float positives = (float)max(n_pos, 1);
@@ -302,14 +344,24 @@ int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_
   RK_CHECK_ARG((int64_t)P * Kin <= MERGE_MAX, "too many candidates per user (%lld > %d)",
                (long long)P * Kin, MERGE_MAX);
   RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
-  const int grid = (int)rk::ceil_div(n_users, 4);
-  const size_t lds = (size_t)4 * 2 * P * Kin * sizeof(float);
-  if (sorted_lists)
-    topk_merge_sorted_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
-                                                   sel.cap, rows_per_user, out_scores, out_ids);
+  // the compacted launch has few rows (a whole workgroup each); everything else a wavefront per row
+  const int rpw = rows_per_user > 0 ? 1 : 4;
+  const int grid = (int)std::min<int64_t>(rk::ceil_div(n_users, rpw), 8 * (int64_t)cu_count());
+  const size_t lds = (size_t)rpw * 2 * P * Kin * sizeof(float);
+  // (measured on the compacted launch's 16 x 20 entries per row: bisection 34 us per launch,
+  // counting all pairs with the whole workgroup 55 us -- a compare is ~100 cycles of branches)
+  if (sorted_lists && rpw == 1)
+    topk_merge_sorted_kernel<1><<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
+                                                      sel.cap, rows_per_user, out_scores, out_ids);
+  else if (sorted_lists)
+    topk_merge_sorted_kernel<4><<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
+                                                      sel.cap, rows_per_user, out_scores, out_ids);
+  else if (rpw == 1)
+    topk_merge_kernel<1><<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
+                                               sel.cap, rows_per_user, out_scores, out_ids);
   else
-    topk_merge_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
-                                            sel.cap, rows_per_user, out_scores, out_ids);
+    topk_merge_kernel<4><<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
+                                               sel.cap, rows_per_user, out_scores, out_ids);
   RK_CHECK_LAUNCH("topk_merge_kernel");
   return RK_OK;
 }
@@ -359,7 +411,7 @@ constexpr int kOpenCap = 1024;
 inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpenCap, rk::ceil_div(n_users, UPB) * UPB); }
 inline int open_nsplit(int32_t n_items, int32_t K) {
   const int64_t tiles = rk::ceil_div(n_items, TI);
-  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(128, tiles / 4));
+  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(256, tiles / 4));
   if (want <= kMergeGroup) return (int)want;               // one merge
   return (int)(want / kMergeGroup * kMergeGroup);          // two: whole groups
 }
@@ -517,11 +569,14 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, uhalf, n_users, ihalf, n_items, mask_ptr, mask_items,
                                    fsplit, direct ? cand_s : ps, direct ? cand_id : pi)) != RK_OK)
     return rc;
-  if (!direct &&
+  // two slices: the refine kernel merges the two lists itself; more: a merge launch first
+  const bool merge_in_refine = !direct && fsplit == 2 && n_items >= kc;
+  if (!direct && !merge_in_refine &&
       (rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, 0, cand_s, cand_id, st)) != RK_OK)
     return rc;
   // 3. exact scores of the candidates, final order, certification
-  if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, std::min(kc, n_items), K, unorm,
+  if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, merge_in_refine ? ps : cand_s,
+                                  merge_in_refine ? pi : cand_id, merge_in_refine ? 2 : 1, std::min(kc, n_items), K, unorm,
                                   uexp, istats, item_id_offset, out_scores, out_ids, done, open_count, open_list,
                                   kOpenCap, st)) != RK_OK)
     return rc;

@@ -158,10 +158,23 @@ __device__ __forceinline__ bool ranks_before(float sa, int32_t ia, float sb, int
   return sa > sb || (sa == sb && ia < ib);
 }
 
-// half a wavefront per user, one lane per candidate (kc <= 32)
+// order of two entries of the candidate lists as the list merge defines it: real entries by (score
+// desc, id asc), padding (id < 0) behind them in list position order
+__device__ __forceinline__ bool list_beats(float sa, int32_t ia, int ja, float sb, int32_t ib, int jb) {
+  const bool va = ia >= 0, vb = ib >= 0;
+  if (va != vb) return va;
+  if (!va) return ja < jb;
+  return sa > sb || (sa == sb && (ia < ib || (ia == ib && ja < jb)));
+}
+
+// half a wavefront per user, one lane per candidate (kc <= 32).  P = 1: cand_* holds one list of kc
+// per user.  P = 2: it holds the sorted lists of two item slices per user ([user][2][kc]), and the
+// half-wavefront first merges them to the best kc by filter score (every entry's rank = its place in
+// its own list + a bisection of the other list through lane shuffles; the same order and padding
+// rules as the list merge kernel) instead of a merge launch writing that list and this one reading it.
 __global__ __launch_bounds__(256) void refine_kernel(
     const float *__restrict__ Uemb, const float *__restrict__ Iemb, int32_t n_users, int32_t n_items, int D,
-    const float *__restrict__ cand_s, const int32_t *__restrict__ cand_id, int kc, int K,
+    const float *__restrict__ cand_s, const int32_t *__restrict__ cand_id, int P, int kc, int K,
     const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
     int32_t item_id_offset, float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
     int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
@@ -172,9 +185,55 @@ __global__ __launch_bounds__(256) void refine_kernel(
   const bool user_ok = user < n_users;
   int32_t id = -1;
   float approx = -INFINITY;
-  if (user_ok && l32 < kc) {
-    id = cand_id[(int64_t)user * kc + l32];
-    approx = cand_s[(int64_t)user * kc + l32];
+  if (P == 1) {
+    if (user_ok && l32 < kc) {
+      id = cand_id[(int64_t)user * kc + l32];
+      approx = cand_s[(int64_t)user * kc + l32];
+    }
+  } else {
+    __shared__ float m_s[8][32];
+    __shared__ int32_t m_id[8][32];
+    float sa = -INFINITY, sb = -INFINITY;
+    int32_t ia = -1, ib = -1;
+    if (user_ok && l32 < kc) {
+      const int64_t base = (int64_t)user * 2 * kc + l32;
+      sa = cand_s[base];
+      ia = cand_id[base];
+      sb = cand_s[base + kc];
+      ib = cand_id[base + kc];
+    }
+    // entries of the other list that come before this lane's entry: bisection with a fixed trip
+    // count (kc <= 32), every lane shuffling in every round
+    int lo_a = 0, hi_a = kc, lo_b = 0, hi_b = kc;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int mid_a = (lo_a + hi_a) >> 1, mid_b = (lo_b + hi_b) >> 1;
+      const float sbm = __shfl(sb, mid_a & 31, 32), sam = __shfl(sa, mid_b & 31, 32);
+      const int32_t ibm = __shfl(ib, mid_a & 31, 32), iam = __shfl(ia, mid_b & 31, 32);
+      if (lo_a < hi_a) {
+        if (list_beats(sbm, ibm, kc + mid_a, sa, ia, l32)) lo_a = mid_a + 1; else hi_a = mid_a;
+      }
+      if (lo_b < hi_b) {
+        if (list_beats(sam, iam, mid_b, sb, ib, kc + l32)) lo_b = mid_b + 1; else hi_b = mid_b;
+      }
+    }
+    const int hw = wave * 2 + sub, rank_a = l32 + lo_a, rank_b = l32 + lo_b;
+    if (l32 < kc) {
+      if (rank_a < kc) {
+        m_s[hw][rank_a] = ia >= 0 ? sa : -INFINITY;
+        m_id[hw][rank_a] = ia;
+      }
+      if (rank_b < kc) {
+        m_s[hw][rank_b] = ib >= 0 ? sb : -INFINITY;
+        m_id[hw][rank_b] = ib;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wavefront's LDS writes are done
+    if (user_ok && l32 < kc) {
+      approx = m_s[hw][l32];
+      id = m_id[hw][l32];
+    }
   }
   const bool valid = id >= 0;
   const bool masked = approx == kMasked;   // (a product of fp16 rows is at most D in magnitude)
@@ -292,11 +351,11 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 }
 
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
-                      const float *cand_s, const int32_t *cand_id, int kc, int K, const float *unorm,
+                      const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const float *unorm,
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
                       int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
                       int32_t open_cap, hipStream_t st) {
-  refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, kc, K,
+  refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, P, kc, K,
                                                                  unorm, uexp, istats, item_id_offset, out_s, out_id, done,
                                                                  open_count, open_list, open_cap);
   RK_CHECK_LAUNCH("refine_kernel");

@@ -618,6 +618,21 @@ def topk_merge(scores, ids, K):
     return out_s, out_i
 
 
+_disc_cache = {}
+
+
+def _discounts(kmax, dev):
+    """1 / log2(rank + 1) for ranks 1..kmax exactly as evalue/metric.py:130-131 builds them (fp32
+    torch ops on the host), kept on the device: a host-to-device copy per evaluation would make the
+    host wait for everything queued before it."""
+    key = (int(kmax), str(dev))
+    d = _disc_cache.get(key)
+    if d is None:
+        d = (1.0 / torch.log2(torch.arange(1, kmax + 1).float() + 1.0)).to(dev)
+        _disc_cache[key] = d
+    return d
+
+
 def rank_metrics(topk_ids, tgt_ptr, tgt_items, k_list, mean_denominator=None, return_sums=False):
     """evaluate_all_at_k for all k at once -> fp32 tensor [len(k_list), 6]
     (precision, recall, hit_rate, ndcg, map, mrr), means over the rows."""
@@ -629,8 +644,7 @@ def rank_metrics(topk_ids, tgt_ptr, tgt_items, k_list, mean_denominator=None, re
     nk = len(k_list)
     dev = topk_ids.device
     kmax = max(k_list)
-    # discounts exactly as evalue/metric.py:130-131 builds them (fp32 torch ops)
-    disc = (1.0 / torch.log2(torch.arange(1, kmax + 1).float() + 1.0)).to(dev)
+    disc = _discounts(kmax, dev)
     lib = _ffi.load()
     ws_bytes = lib.rk_rank_metrics_ws_bytes(n_users, nk)
     ws = torch.empty(ws_bytes // 8 + 2, dtype=torch.float64, device=dev)
