@@ -7,7 +7,7 @@ from recommend_amd import ops
 
 I, U = 63001, 192403
 dev = "cuda"
-for F in (4096, 384):
+for F in ([int(os.environ["PROJ_F"])] if "PROJ_F" in os.environ else (4096, 384)):
     x = torch.randn(I, F, device=dev)
     w = (torch.randn(64, F, device=dev) / F ** 0.5).requires_grad_(True)
     b = torch.randn(64, device=dev, requires_grad=True)
