@@ -315,12 +315,12 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
     case 1:
       score_topk_kernel<KPAD, 1, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi);
+                                                               gate_cap, ps, pi, 0);
       break;
     case 2:
       score_topk_kernel<KPAD, 2, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi);
+                                                               gate_cap, ps, pi, 0);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)",
@@ -432,9 +432,10 @@ inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
 constexpr int kShortTableTiles = 512;
 inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
   if (rk::ceil_div(n_items, TI) <= kShortTableTiles) return 1;
-  int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
-  if (ns == 1) ns = 2;
-  return std::min(ns, std::max(2, choose_nsplit(n_users, n_items)));
+  // (long tables used to take two slices at least, so that not every workgroup walks the table at
+  // the same position; the filter's workgroups now start at staggered tiles instead)
+  const int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
+  return std::min(ns, std::max(1, choose_nsplit(n_users, n_items)));
 }
 
 // (8 places of margin between the K-th exact and the last filter score, 4 at least)
@@ -576,7 +577,7 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
     return rc;
   // 3. exact scores of the candidates, final order, certification
   if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, merge_in_refine ? ps : cand_s,
-                                  merge_in_refine ? pi : cand_id, merge_in_refine ? 2 : 1, std::min(kc, n_items), K, unorm,
+                                  merge_in_refine ? pi : cand_id, merge_in_refine ? 2 : 1, std::min(kc, n_items), K, mask_ptr, unorm,
                                   uexp, istats, item_id_offset, out_scores, out_ids, done, open_count, open_list,
                                   kOpenCap, st)) != RK_OK)
     return rc;

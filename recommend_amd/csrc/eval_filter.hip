@@ -175,7 +175,7 @@ __device__ __forceinline__ bool list_beats(float sa, int32_t ia, int ja, float s
 __global__ __launch_bounds__(256) void refine_kernel(
     const float *__restrict__ Uemb, const float *__restrict__ Iemb, int32_t n_users, int32_t n_items, int D,
     const float *__restrict__ cand_s, const int32_t *__restrict__ cand_id, int P, int kc, int K,
-    const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
+    const int32_t *__restrict__ mask_ptr, const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
     int32_t item_id_offset, float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
     int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
   const int wave = threadIdx.x / rk::kWave, lane = threadIdx.x % rk::kWave;
@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void refine_kernel(
     // The K-th score must also lie above the mask score: the filter ranks masked items below
     // every real score of its (rescaled) units, the exact kernel ranks them at -1e10, above real
     // scores that are lower still.
-    const bool ok = n_valid == kc && !has_nan && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
+    // (users with very long training lists were not masked by the filter pass: heavy_mask_len)
+    const bool heavy = mask_ptr != nullptr && mask_ptr[user + 1] - mask_ptr[user] > heavy_mask_len(n_items);
+    const bool ok = !heavy && n_valid == kc && !has_nan && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
       const int32_t pos = atomicAdd(open_count, 1);
@@ -286,6 +288,10 @@ __global__ __launch_bounds__(256) void refine_kernel(
   }
 }
 
+// tiles between the starting points of consecutive workgroups of the filter launch (odd, and far
+// from the 3 x 256 workgroups that run at a time, so that concurrent ones spread over the table)
+constexpr int32_t kRotStride = 389;
+
 template <int KC>
 int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_users, const float *Is,
                   int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items, int32_t nsplit,
@@ -293,11 +299,11 @@ int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_u
   switch (DC) {
     case 1:
       score_topk_kernel<KC, 1, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, kRotStride);
       break;
     case 2:
       score_topk_kernel<KC, 2, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, kRotStride);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", 64 * DC);
@@ -351,12 +357,13 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 }
 
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
-                      const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const float *unorm,
+                      const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const int32_t *mask_ptr,
+                      const float *unorm,
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
                       int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
                       int32_t open_cap, hipStream_t st) {
   refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, P, kc, K,
-                                                                 unorm, uexp, istats, item_id_offset, out_s, out_id, done,
+                                                                 mask_ptr, unorm, uexp, istats, item_id_offset, out_s, out_id, done,
                                                                  open_count, open_list, open_cap);
   RK_CHECK_LAUNCH("refine_kernel");
   return RK_OK;

@@ -28,7 +28,8 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 // bound is below the K-th exact score, or every item is a candidate).  The other users are counted
 // in open_count[0] (zeroed by the caller) and the first open_cap of them listed in open_list.
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
-                      const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const float *unorm,
+                      const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const int32_t *mask_ptr,
+                      const float *unorm,
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s, int32_t *out_id,
                       int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
                       hipStream_t st);
