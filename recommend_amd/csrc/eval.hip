@@ -315,12 +315,12 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
     case 1:
       score_topk_kernel<KPAD, 1, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi, 0);
+                                                               gate_cap, ps, pi);
       break;
     case 2:
       score_topk_kernel<KPAD, 2, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi, 0);
+                                                               gate_cap, ps, pi);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)",
@@ -432,8 +432,8 @@ inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
 constexpr int kShortTableTiles = 512;
 inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
   if (rk::ceil_div(n_items, TI) <= kShortTableTiles) return 1;
-  // (long tables used to take two slices at least, so that not every workgroup walks the table at
-  // the same position; the filter's workgroups now start at staggered tiles instead)
+  // (long tables used to take two slices at least: a single slice looked half as fast per tile,
+  // which was one user with a very long training list holding up its workgroup: heavy_mask_len)
   const int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
   return std::min(ns, std::max(1, choose_nsplit(n_users, n_items)));
 }

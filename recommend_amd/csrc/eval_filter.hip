@@ -288,10 +288,6 @@ __global__ __launch_bounds__(256) void refine_kernel(
   }
 }
 
-// tiles between the starting points of consecutive workgroups of the filter launch (odd, and far
-// from the 3 x 256 workgroups that run at a time, so that concurrent ones spread over the table)
-constexpr int32_t kRotStride = 389;
-
 template <int KC>
 int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_users, const float *Is,
                   int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items, int32_t nsplit,
@@ -299,11 +295,11 @@ int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_u
   switch (DC) {
     case 1:
       score_topk_kernel<KC, 1, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, kRotStride);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
       break;
     case 2:
       score_topk_kernel<KC, 2, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, kRotStride);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", 64 * DC);

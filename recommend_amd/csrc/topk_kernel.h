@@ -16,12 +16,13 @@ constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
 constexpr int QS = 8;      // queue slots per lane
 constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
-// A user with more training items than this (about one per tile of the item table on average) is
-// not masked by the filter pass at all and always handed to the exact kernel: a lane that meets
-// three or more masked items in a tile waits for a memory round trip per item, behind the tile
-// prefetch, and one such lane holds up its whole workgroup -- with one slice per user tile, the
-// whole launch (Elec: one user with 45k training items made a 3 ms launch take 6 ms).  The exact
-// kernel meets the same user in the compacted launch, cut into hundreds of item slices.
+// A user with more training items than this (a quarter of an item per tile of the table on average,
+// 512 at least) is not masked by the filter pass at all and always handed to the exact kernel: a
+// lane that meets three or more masked items in a tile waits for a memory round trip per item,
+// behind the tile prefetch, and one such lane holds up its whole workgroup -- with one slice per
+// user tile, the whole launch (Elec: one user with 45k training items made a 3 ms launch take 6 ms,
+// and is why long tables used to be cut into two slices).  The exact kernel meets the same user in
+// the compacted launch, cut into hundreds of item slices.
 __host__ __device__ inline int32_t heavy_mask_len(int32_t n_items) { return max((n_items + 31) / 32 / 4, 512); }
 
 // list length the kernel is compiled for: K rounded up to a multiple of 4 (an insertion costs one
@@ -115,13 +116,6 @@ struct LaneList {
 //   user_list != NULL: position p < *user_count stands for user user_list[p] (row of Uemb and of
 //     the mask); part_* rows are positions; nothing runs if *user_count > gate_cap.  n_users is
 //     then the number of positions the grid covers.
-// rot_stride (FILTER only; 0 = off): workgroup b walks the tiles of its slice starting
-// (b * rot_stride) % tiles into it and wraps around.  All workgroups of a launch walking one long
-// table at the same position ran half as fast per tile, which used to be avoided by cutting the
-// table into two slices -- and every slice restarts the lists and pays their K ln(n/K) insertions
-// again.  The order in which a filter list meets equal scores does not matter: the candidates are
-// re-scored and ordered exactly afterwards, and the certificate only needs the list to hold the
-// best scores of its slice.  (The exact kernel keeps ascending order: there ties go by arrival.)
 #ifdef RK_STAMP
 __device__ inline int n_tiles_stamp(int a, int b) { return b - a; }
 // Diagnostic build: cycles of wavefront lifetime per phase of the filter loop, summed over all
@@ -141,7 +135,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
     int32_t nsplit, int32_t item_id_offset, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    float *__restrict__ part_s, int32_t *__restrict__ part_id, int32_t rot_stride) {
+    float *__restrict__ part_s, int32_t *__restrict__ part_id) {
   constexpr int D = 64 * DC;
   // Exact scores: every wavefront streams its own copy of the item tiles through a private pair
   // of buffers (the MFMA chain is the bound, nothing is shared, no barriers).
@@ -227,33 +221,16 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
       }
   }
 
-  // tiles of this slice in the order this workgroup walks them: position L in [0, nt) is tile phys(L)
-  const int32_t nt = t_hi - t_lo;
-  int32_t rot = 0;
-  if constexpr (FILTER) {
-    if (rot_stride > 0 && nt > 0) rot = (int32_t)(((int64_t)utile * rot_stride) % nt);
-  }
-  auto phys = [&](int32_t L) {
-    int32_t p = L + rot;
-    if (p >= nt) p -= nt;
-    return t_lo + p;
-  };
-
   // train-mask cursor of this lane's user (item ids ascending)
-  int32_t mbegin = 0, mcur = 0, mend = 0;
+  int32_t mcur = 0, mend = 0;
   if (mask_ptr && user_ok) {
-    mbegin = mask_ptr[row_l];
+    mcur = mask_ptr[row_l];
     mend = mask_ptr[row_l + 1];
     if constexpr (FILTER) {
-      if (mend - mbegin > heavy_mask_len(n_items)) mbegin = mend;   // left to the exact kernel, see heavy_mask_len
+      if (mend - mcur > heavy_mask_len(n_items)) mcur = mend;   // left to the exact kernel, see heavy_mask_len
     }
-  }
-  // The cursor holds the next TWO masked items: the entry consumed in a tile was loaded at
-  // least one consumption earlier, so the loop below does not sit out a memory round trip
-  // (behind every DMA in flight -- the counter is in order) for each masked item of the tile.
-  int32_t next_m = INT32_MAX, next2_m = INT32_MAX;
-  auto seek_mask = [&](int32_t first) {   // cursor to the first masked item >= first
-    int32_t lo = mbegin, hi = mend;
+    int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
+    const int32_t first = t_lo * TI;
     while (lo < hi) {
       const int32_t mid = (lo + hi) >> 1;
       if (mask_items[mid] < first)
@@ -262,10 +239,12 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
         hi = mid;
     }
     mcur = lo;
-    next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
-    next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
-  };
-  seek_mask((nt > 0 ? phys(0) : t_lo) * TI);
+  }
+  // The cursor holds the next TWO masked items: the entry consumed in a tile was loaded at
+  // least one consumption earlier, so the loop below does not sit out a memory round trip
+  // (behind every DMA in flight -- the counter is in order) for each masked item of the tile.
+  int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+  int32_t next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
 
 #ifdef RK_STAMP
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -474,16 +453,16 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
       const uint32_t a = frag_off ^ (uint32_t)((2 * kb) * 16);
       fi[kb & 1] = __builtin_bit_cast(half8, *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(src) + a));
     };
-    auto issue_stage = [&](int32_t first, int half_idx) {   // positions first .. first + RN - 1
+    auto issue_stage = [&](int32_t first, int half_idx) {
 #pragma unroll
-      for (int j = 0; j < RN; ++j) issue_tile(phys(min(first + j, nt - 1)), ring[half_idx * RN + j]);
+      for (int j = 0; j < RN; ++j) issue_tile(min(first + j, t_hi - 1), ring[half_idx * RN + j]);
     };
     // The user fragments and the mask cursor are global loads too: all of them have to be back
     // before the in-order counter is used to tell the stages apart.
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (nt > 0) issue_stage(0, 0);
+    if (t_lo < t_hi) issue_stage(t_lo, 0);
     int half_idx = 0;
-    for (int32_t tb = 0; tb < nt; tb += RN, half_idx ^= 1) {
+    for (int32_t tb = t_lo; tb < t_hi; tb += RN, half_idx ^= 1) {
       RK_T(s0);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       RK_T(s1);
@@ -495,9 +474,8 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
       RK_ACC(0, s0, s1); RK_ACC(1, s1, s2); RK_ACC(2, s2, s3);
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
-        if (tb + j >= nt) break;                   // uniform over the workgroup
-        const int32_t t = phys(tb + j);
-        if (rot != 0 && tb + j == nt - rot) seek_mask(t_lo * TI);   // wrapped around to the slice's first tile
+        const int32_t t = tb + j;
+        if (t >= t_hi) break;                      // uniform over the workgroup
         const float *cur = ring[half_idx * RN + j];
         asm volatile("" : "+v"(frag_off));         // as for lane_off: hoisted addresses cost registers
         RK_T(p0);
