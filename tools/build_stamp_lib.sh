@@ -9,4 +9,4 @@ cd "$root/recommend_amd/csrc"
   -Wno-inline-asm -DRK_STAMP -c eval_filter.hip -o /tmp/ef_stamp.o
 cd ../lib
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/_variants/lib_stamp.so" \
-  host.cpp.o graph.hip.o spmm.hip.o dense.hip.o glue.hip.o bpr.hip.o eval.hip.o proj.hip.o /tmp/ef_stamp.o
+  $(ls *.o | grep -v '^eval_filter.hip.o$') /tmp/ef_stamp.o
