@@ -315,12 +315,12 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
     case 1:
       score_topk_kernel<KPAD, 1, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi);
+                                                               gate_cap, ps, pi, nullptr);
       break;
     case 2:
       score_topk_kernel<KPAD, 2, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
                                                                mask_items, nsplit, off, skip, user_list, user_count,
-                                                               gate_cap, ps, pi);
+                                                               gate_cap, ps, pi, nullptr);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)",
@@ -433,7 +433,7 @@ constexpr int kShortTableTiles = 512;
 inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
   if (rk::ceil_div(n_items, TI) <= kShortTableTiles) return 1;
   // (long tables used to take two slices at least: a single slice looked half as fast per tile,
-  // which was one user with a very long training list holding up its workgroup: heavy_mask_len)
+  // which was one user with a very long training list holding up its workgroup: kHeavyUsers)
   const int ns = choose_nsplit(n_users, n_items, wg_per_cu(kc, D / 64, true));
   return std::min(ns, std::max(1, choose_nsplit(n_users, n_items)));
 }
@@ -444,7 +444,7 @@ inline int filter_len(int K) { return K + 8 <= 32 ? std::max(8, kpad_for(K + 8))
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct TopkWorkspace {
-  size_t part, uhalf, ihalf, unorm, umax, uexp, istats, open_count, stats_part, open_list, cand_s, cand_id, done, total;
+  size_t part, uhalf, ihalf, unorm, umax, uexp, istats, open_count, heavy, stats_part, open_list, cand_s, cand_id, done, total;
 };
 inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
   TopkWorkspace w{};
@@ -463,6 +463,7 @@ inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D,
   w.uexp = off;    off += align256((size_t)n_users * 4);
   w.istats = off;  off += 128;   // item statistics and open_count share one 256-byte block, zeroed together
   w.open_count = off; off += 128;
+  w.heavy = off;      off += 256;   // histogram of training-list lengths + the heavy-user threshold (zeroed with the rest)
   w.stats_part = off; off += align256((size_t)2 * rk::kStatSlots * 4);   // follows directly: one memset
   w.open_list = off;  off += align256((size_t)kOpenCap * 4);
   w.cand_s = off;  off += align256((size_t)n_users * std::max(kc, 1) * 4);
@@ -556,7 +557,10 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   int32_t *open_count = (int32_t *)(base + w.open_count), *open_list = (int32_t *)(base + w.open_list);
 
   // 1. fp16 copies of both tables; user norms and the largest item norm for the error bound
-  RK_CHECK_HIP(hipMemsetAsync(istats, 0, 256 + 2 * rk::kStatSlots * 4, st));   // statistics, open_count, partial maxima
+  RK_CHECK_HIP(hipMemsetAsync(istats, 0, 512 + 2 * rk::kStatSlots * 4, st));   // statistics, open_count, heavy, partial maxima
+  int32_t *heavy = mask_ptr ? (int32_t *)(base + w.heavy) : nullptr;
+  if (heavy && (rc = rk::heavy_threshold(mask_ptr, n_users, n_items, heavy, st)) != RK_OK) return rc;
+  const int32_t *heavy_thresh = heavy ? heavy + 32 : nullptr;
   unsigned int *stats_part = (unsigned int *)(base + w.stats_part);
   if ((rc = rk::half_rows(Uemb, n_users, D, true, uhalf, unorm, umax, uexp, nullptr, nullptr, st)) != RK_OK) return rc;
   if ((rc = rk::half_rows(Iemb, n_items, D, false, ihalf, nullptr, nullptr, nullptr, stats_part, istats, st)) != RK_OK)
@@ -568,7 +572,7 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   // a single slice's lists ARE the candidates (sorted, unfilled places -inf / -1): no merge
   const bool direct = fsplit == 1 && n_items >= kc;
   if ((rc = rk::launch_filter_topk(kc, D / 64, grid, st, uhalf, n_users, ihalf, n_items, mask_ptr, mask_items,
-                                   fsplit, direct ? cand_s : ps, direct ? cand_id : pi)) != RK_OK)
+                                   fsplit, direct ? cand_s : ps, direct ? cand_id : pi, heavy_thresh)) != RK_OK)
     return rc;
   // two slices: the refine kernel merges the two lists itself; more: a merge launch first
   const bool merge_in_refine = !direct && fsplit == 2 && n_items >= kc;
@@ -577,7 +581,8 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
     return rc;
   // 3. exact scores of the candidates, final order, certification
   if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, merge_in_refine ? ps : cand_s,
-                                  merge_in_refine ? pi : cand_id, merge_in_refine ? 2 : 1, std::min(kc, n_items), K, mask_ptr, unorm,
+                                  merge_in_refine ? pi : cand_id, merge_in_refine ? 2 : 1, std::min(kc, n_items), K, mask_ptr,
+                                  heavy_thresh, unorm,
                                   uexp, istats, item_id_offset, out_scores, out_ids, done, open_count, open_list,
                                   kOpenCap, st)) != RK_OK)
     return rc;

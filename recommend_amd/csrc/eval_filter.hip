@@ -175,7 +175,7 @@ __device__ __forceinline__ bool list_beats(float sa, int32_t ia, int ja, float s
 __global__ __launch_bounds__(256) void refine_kernel(
     const float *__restrict__ Uemb, const float *__restrict__ Iemb, int32_t n_users, int32_t n_items, int D,
     const float *__restrict__ cand_s, const int32_t *__restrict__ cand_id, int P, int kc, int K,
-    const int32_t *__restrict__ mask_ptr, const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ heavy_thresh, const float *__restrict__ unorm, const int32_t *__restrict__ uexp, const float *__restrict__ istats,
     int32_t item_id_offset, float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
     int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
   const int wave = threadIdx.x / rk::kWave, lane = threadIdx.x % rk::kWave;
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void refine_kernel(
     // The K-th score must also lie above the mask score: the filter ranks masked items below
     // every real score of its (rescaled) units, the exact kernel ranks them at -1e10, above real
     // scores that are lower still.
-    // (users with very long training lists were not masked by the filter pass: heavy_mask_len)
-    const bool heavy = mask_ptr != nullptr && mask_ptr[user + 1] - mask_ptr[user] > heavy_mask_len(n_items);
+    // (users with very long training lists were not masked by the filter pass: kHeavyUsers)
+    const bool heavy = heavy_thresh != nullptr && mask_ptr[user + 1] - mask_ptr[user] > heavy_thresh[0];
     const bool ok = !heavy && n_valid == kc && !has_nan && (kc >= n_items || (a_min + eps < tau && tau > kMasked));
     done[user] = ok ? 1 : 0;
     if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
@@ -288,18 +288,44 @@ __global__ __launch_bounds__(256) void refine_kernel(
   }
 }
 
+// hist[b]: users whose training list has bit length b (length in [2^(b-1), 2^b))
+__global__ __launch_bounds__(256) void mask_hist_kernel(const int32_t *__restrict__ mask_ptr, int32_t n_users,
+                                                        int32_t *__restrict__ hist) {
+  __shared__ int32_t h[32];
+  if (threadIdx.x < 32) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int32_t u = blockIdx.x * 256 + threadIdx.x;
+  if (u < n_users) {
+    const int32_t len = mask_ptr[u + 1] - mask_ptr[u];
+    if (len > 0) atomicAdd(&h[32 - __clz(len)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && h[threadIdx.x] != 0) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// heavy[32] = the smallest 2^(b-1) - 1 with at most kHeavyUsers users of bit length >= b, raised to `floor_len`
+__global__ void heavy_thresh_kernel(int32_t *__restrict__ heavy, int32_t floor_len) {
+  int32_t above = 0, b = 32;
+  while (b > 1 && above + heavy[b - 1] <= kHeavyUsers) {
+    --b;
+    above += heavy[b];
+  }
+  // bit lengths >= b are heavy: lengths > 2^(b-1) - 1
+  const int32_t t = b >= 32 ? INT32_MAX : (int32_t)((1u << (b - 1)) - 1u);
+  heavy[32] = max(t, floor_len);
+}
+
 template <int KC>
 int launch_filter(int DC, int grid, hipStream_t st, const float *Us, int32_t n_users, const float *Is,
                   int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items, int32_t nsplit,
-                  float *ps, int32_t *pi) {
+                  float *ps, int32_t *pi, const int32_t *heavy_thresh) {
   switch (DC) {
     case 1:
       score_topk_kernel<KC, 1, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, heavy_thresh);
       break;
     case 2:
       score_topk_kernel<KC, 2, true><<<grid, 256, 0, st>>>(Us, n_users, Is, n_items, mask_ptr, mask_items,
-                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi);
+                                                            nsplit, 0, nullptr, nullptr, nullptr, 0, ps, pi, heavy_thresh);
       break;
     default:
       return rk::fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", 64 * DC);
@@ -337,29 +363,38 @@ int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *o
   return RK_OK;
 }
 
+int heavy_threshold(const int32_t *mask_ptr, int32_t n_users, int32_t n_items, int32_t *heavy, hipStream_t st) {
+  mask_hist_kernel<<<(unsigned)ceil_div(n_users, 256), 256, 0, st>>>(mask_ptr, n_users, heavy);
+  RK_CHECK_LAUNCH("mask_hist_kernel");
+  heavy_thresh_kernel<<<1, 1, 0, st>>>(heavy, std::max(ceil_div(n_items, TI) / 4, (int64_t)32));
+  RK_CHECK_LAUNCH("heavy_thresh_kernel");
+  return RK_OK;
+}
+
 int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Usplit, int32_t n_users,
                        const float *Isplit, int32_t n_items, const int32_t *mask_ptr,
-                       const int32_t *mask_items, int32_t nsplit, float *ps, int32_t *pi) {
+                       const int32_t *mask_items, int32_t nsplit, float *ps, int32_t *pi,
+                       const int32_t *heavy_thresh) {
   switch (kc) {
-    case 8: return launch_filter<8>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 12: return launch_filter<12>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 16: return launch_filter<16>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 20: return launch_filter<20>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 24: return launch_filter<24>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 28: return launch_filter<28>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
-    case 32: return launch_filter<32>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi);
+    case 8: return launch_filter<8>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 12: return launch_filter<12>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 16: return launch_filter<16>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 20: return launch_filter<20>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 24: return launch_filter<24>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 28: return launch_filter<28>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
+    case 32: return launch_filter<32>(DC, grid, st, Usplit, n_users, Isplit, n_items, mask_ptr, mask_items, nsplit, ps, pi, heavy_thresh);
     default: return fail(RK_ERR_UNSUPPORTED, "top-K filter: candidate list length %d not built", kc);
   }
 }
 
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
                       const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const int32_t *mask_ptr,
-                      const float *unorm,
+                      const int32_t *heavy_thresh, const float *unorm,
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
                       int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
                       int32_t open_cap, hipStream_t st) {
   refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, P, kc, K,
-                                                                 mask_ptr, unorm, uexp, istats, item_id_offset, out_s, out_id, done,
+                                                                 mask_ptr, heavy_thresh, unorm, uexp, istats, item_id_offset, out_s, out_id, done,
                                                                  open_count, open_list, open_cap);
   RK_CHECK_LAUNCH("refine_kernel");
   return RK_OK;

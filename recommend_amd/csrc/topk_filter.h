@@ -20,7 +20,13 @@ int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *o
 // item ids local to this table.
 int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Usplit, int32_t n_users,
                        const float *Isplit, int32_t n_items, const int32_t *mask_ptr,
-                       const int32_t *mask_items, int32_t nsplit, float *part_s, int32_t *part_id);
+                       const int32_t *mask_items, int32_t nsplit, float *part_s, int32_t *part_id,
+                       const int32_t *heavy_thresh);
+
+// heavy[0..31] (zeroed by the caller): histogram of the users' training-list lengths by bit length;
+// heavy[32] receives the length above which a user skips the filter pass: at least a quarter of an
+// item per tile of the table (32 at least), and such that at most kHeavyUsers users are above it.
+int heavy_threshold(const int32_t *mask_ptr, int32_t n_users, int32_t n_items, int32_t *heavy, hipStream_t st);
 
 // Exact fp32 scores of each user's kc candidates, the best K of them by (score desc, id asc)
 // written to out (ids + item_id_offset), and done[user] = 1 iff no item outside the candidates
@@ -29,7 +35,7 @@ int launch_filter_topk(int kc, int DC, int grid, hipStream_t st, const float *Us
 // in open_count[0] (zeroed by the caller) and the first open_cap of them listed in open_list.
 int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
                       const float *cand_s, const int32_t *cand_id, int P, int kc, int K, const int32_t *mask_ptr,
-                      const float *unorm,
+                      const int32_t *heavy_thresh, const float *unorm,
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s, int32_t *out_id,
                       int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
                       hipStream_t st);

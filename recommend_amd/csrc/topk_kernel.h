@@ -16,14 +16,16 @@ constexpr int UPB = 256;   // users per workgroup (4 independent wavefronts)
 constexpr int QS = 8;      // queue slots per lane
 constexpr float kMasked = -1e10f;  // evalue/evaluator.py:55
 
-// A user with more training items than this (a quarter of an item per tile of the table on average,
-// 512 at least) is not masked by the filter pass at all and always handed to the exact kernel: a
-// lane that meets three or more masked items in a tile waits for a memory round trip per item,
-// behind the tile prefetch, and one such lane holds up its whole workgroup -- with one slice per
-// user tile, the whole launch (Elec: one user with 45k training items made a 3 ms launch take 6 ms,
-// and is why long tables used to be cut into two slices).  The exact kernel meets the same user in
-// the compacted launch, cut into hundreds of item slices.
-__host__ __device__ inline int32_t heavy_mask_len(int32_t n_items) { return max((n_items + 31) / 32 / 4, 512); }
+// Users with very long training lists are not masked by the filter pass at all and always handed
+// to the exact kernel: a lane that meets three or more masked items in a tile waits for a memory
+// round trip per item, behind the tile prefetch, and one such lane holds up its whole workgroup --
+// with one slice per user tile, the whole launch (Elec: one user with 45k training items made a
+// 3 ms launch take 6 ms, and is why long tables used to be cut into two slices).  The exact kernel
+// meets the same users in the compacted launch, cut into hundreds of item slices.  "Very long" is
+// more than heavy_thresh[0] items, a device value computed per call (heavy_threshold() in
+// eval_filter.hip): at least a quarter of an item per tile of the table, and high enough that no
+// more than kHeavyUsers users are above it, whatever the data set looks like.
+constexpr int kHeavyUsers = 512;
 
 // list length the kernel is compiled for: K rounded up to a multiple of 4 (an insertion costs one
 // step per list entry, and a longer list also lowers the threshold that filters candidates)
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
     int32_t nsplit, int32_t item_id_offset, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    float *__restrict__ part_s, int32_t *__restrict__ part_id) {
+    float *__restrict__ part_s, int32_t *__restrict__ part_id, const int32_t *__restrict__ heavy_thresh) {
   constexpr int D = 64 * DC;
   // Exact scores: every wavefront streams its own copy of the item tiles through a private pair
   // of buffers (the MFMA chain is the bound, nothing is shared, no barriers).
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     mcur = mask_ptr[row_l];
     mend = mask_ptr[row_l + 1];
     if constexpr (FILTER) {
-      if (mend - mcur > heavy_mask_len(n_items)) mcur = mend;   // left to the exact kernel, see heavy_mask_len
+      if (heavy_thresh != nullptr && mend - mcur > heavy_thresh[0]) mcur = mend;   // left to the exact kernel (kHeavyUsers)
     }
     int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
     const int32_t first = t_lo * TI;

@@ -125,6 +125,31 @@ def test_filtered_ranking_equals_exact_kernel(U, I, D, K, scale):
     np.testing.assert_array_equal(fs[:64].cpu().numpy(), o_s)
 
 
+@pytest.mark.parametrize("dense_users", [40, 3000])
+def test_users_with_long_training_lists_skip_the_filter(dense_users):
+    """Users with very long training lists are not masked by the filter pass and are ranked by the
+    exact kernel's compacted launch; how long is "very long" adapts so that at most 512 users
+    qualify.  A few heavy users (all of them skip) and a data set where most users are heavy (the
+    threshold rises, the rest are masked in the filter as usual): the exact kernel's bits either way."""
+    U, I, D, K = 3200, 8192, 64, 20
+    g = torch.Generator().manual_seed(dense_users)
+    ue, ie = (torch.randn(U, D, generator=g) * 0.1).to(DEV), (torch.randn(I, D, generator=g) * 0.1).to(DEV)
+    rng = np.random.default_rng(dense_users)
+    rows, cols = [rng.integers(0, U, 10 * U)], [rng.integers(0, I, 10 * U)]
+    for u in range(dense_users):                       # 100 .. 4000 masked items each
+        n = int(rng.integers(100, 4000))
+        rows.append(np.full(n, u * (U // dense_users)))
+        cols.append(rng.choice(I, n, replace=False))
+    ptr, mcols = pairs_to_csr(np.concatenate(rows), np.concatenate(cols), U)
+    fs, fi = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), mode="filter")
+    es, ei = ops.score_topk(ue, ie, K, dev(ptr), dev(mcols), mode="exact")
+    assert torch.equal(fi, ei)
+    assert torch.equal(fs.view(torch.int32), es.view(torch.int32))
+    o_s, o_i = eval_oracle.score_topk(ue[:40].cpu().numpy(), ie.cpu().numpy(), K, ptr[:41], mcols[:ptr[40]])
+    np.testing.assert_array_equal(fi[:40].cpu().numpy(), o_i)
+    np.testing.assert_array_equal(fs[:40].cpu().numpy(), o_s)
+
+
 @pytest.mark.parametrize("U", [300, 1500])
 def test_filter_falls_back_when_nothing_can_be_certified(U):
     """All-zero users tie every item (nobody certified: few users go through the compacted exact
