@@ -383,12 +383,15 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 32).
  *
  * All three entry points return the same bits; they differ in how they get there.
- * rk_score_topk_exact_f32 ranks every score on the exact kernel.
+ * rk_score_topk_exact_f32 ranks every score on the exact kernel (D = 64 or 128: user rows resident
+ * in registers; any other multiple of 64, e.g. the reference's default emb_dim 256: the kernel of
+ * rk_score_topk_wide_f32, which walks the width in chunks, with the mask).
  * rk_score_topk_filtered_f32 (K <= 28, D = 64 or 128; otherwise it is the exact one) first ranks
  * by fp16 scores (both tables copied to fp16, one fp16 MFMA per 16 k), keeps the K+8 best per
  * user, re-scores those candidates with the exact chain, and runs the exact kernel only for users
  * whose result that procedure cannot certify (a candidate's fp16 score within the fp16 error bound
- * of the K-th exact score: ties at the K-th place, non-finite embeddings).
+ * of the K-th exact score: ties at the K-th place, non-finite embeddings) and for the (at most
+ * 512) users with the longest training lists, which the filter pass does not mask.
  * rk_score_topk_f32 picks between the two by size (the filter pays off from ~5*10^8 scores).
  * All take the same workspace. */
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D,

@@ -22,6 +22,7 @@
 // per-slice lists orders by (score desc, id asc) explicitly.
 #include <cstdlib>
 #include "topk_filter.h"
+#include "topk_wide.h"
 #include "topk_kernel.h"
 
 namespace {
@@ -454,8 +455,9 @@ inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D,
   const size_t klen = (size_t)std::max(kpad_for(K), kc);
   size_t off = 0;
   w.part = off;
-  off += align256(std::max((size_t)n_users * std::max(nsplit, 2) * klen,
-                           open_part_entries(n_users, n_items, K)) * 8);
+  size_t part_entries = std::max((size_t)n_users * std::max(nsplit, 2) * klen, open_part_entries(n_users, n_items, K));
+  if (D != 64 && D != 128) part_entries = std::max(part_entries, rk::wide_part_entries(n_users, n_items, K));
+  off += align256(part_entries * 8);
   w.uhalf = off;   off += align256((size_t)n_users * D * 2);
   w.ihalf = off;   off += align256((size_t)n_items * D * 2);
   w.unorm = off;   off += align256((size_t)n_users * 4);
@@ -514,6 +516,10 @@ int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users, const float *Iem
                                  out_ids, ws, ws_bytes);
   if (rc != RK_OK) return rc;
   const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
+  // widths the register-resident kernel is not built for: the kernel that walks the width in chunks
+  if (D != 64 && D != 128)
+    return rk::wide_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset, out_scores, out_ids,
+                         (float *)((char *)ws + w.part), (hipStream_t)stream);
   return exact_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
                     choose_nsplit(n_users, n_items), UserSel{}, out_scores, out_ids,
                     (float *)((char *)ws + w.part), (hipStream_t)stream);

@@ -13,9 +13,14 @@
 // seen the whole width are its scores offered to the per-lane sorted lists (one user per lane after
 // a half swap, as in the evaluation kernel; ties go to the lower id).  Per 64-float chunk a
 // workgroup loads 96 KB for 4.2 Mflop, i.e. the launch is bound by the fp32-input MFMA rate.
+//
+// The same kernel ranks users against items for embedding widths the evaluation kernel is not built
+// for (rk_score_topk_f32 with D = 192, 256, ...): it then takes the train mask (CSR per A row, sorted;
+// masked pairs score -1e10, evalue/evaluator.py:55) and the id offset of an item shard.
 #include <algorithm>
 
 #include "topk_kernel.h"
+#include "topk_wide.h"
 
 namespace {
 
@@ -28,6 +33,7 @@ constexpr int LDB = CH + 4;    // LDS row pitch in floats (shifts consecutive ro
 template <int KPAD>
 __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
     const float *__restrict__ A, int32_t n_a, const float *__restrict__ B, int32_t n_b, int32_t F,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items, int32_t id_offset,
     int32_t nsplit, float *__restrict__ part_s, int32_t *__restrict__ part_id) {
   __shared__ __attribute__((aligned(16))) float Bs[2][GI][LDB];
 
@@ -51,6 +57,24 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
   LaneList<KPAD> list;
   list.init();
   float thr = -INFINITY;
+
+  // train-mask cursor of this lane's row of A (item ids ascending), at the first entry of this slice
+  int32_t mcur = 0, mend = 0;
+  if (mask_ptr != nullptr && user < n_a) {
+    mcur = mask_ptr[user];
+    mend = mask_ptr[user + 1];
+    const int32_t first = g_lo * GI;
+    int32_t lo = mcur, hi = mend;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (mask_items[mid] < first)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    mcur = lo;
+  }
+  int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
 
   // registers of the step in flight: this thread's 8 float4 of the next B chunk (row e / 16,
   // float4 e % 16 for e = tid + 256 i) and the next A chunk of the two user columns of this lane
@@ -138,6 +162,14 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
       __syncthreads();
     }
     // the group has seen the whole width: offer its 128 scores per user, ascending ids
+    uint32_t mbits[GT] = {0u, 0u, 0u, 0u};   // masked items of this lane's user among the group's 128
+    while (next_m < (g + 1) * GI) {
+      const int32_t rel = next_m - g * GI;
+#pragma unroll
+      for (int j = 0; j < GT; ++j) mbits[j] |= (rel >> 5) == j ? 1u << (rel & 31) : 0u;
+      ++mcur;
+      next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
+    }
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       // lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in
@@ -162,6 +194,7 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
           for (int i = 0; i < 8; ++i) {
             const int32_t id = item0 + 8 * q + i;
             float v = i < 4 ? lo[4 * q + i] : hi[4 * q + i - 4];
+            if ((mbits[j] >> (8 * q + i)) & 1u) v = kMasked;
             if (id >= n_b) v = -INFINITY;
             if (__any(v > thr)) {
               list.insert(v, id);
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
 #pragma unroll
     for (int j = 0; j < KPAD; ++j) {
       part_s[base + j] = list.s[j];
-      part_id[base + j] = list.id[j];
+      part_id[base + j] = list.id[j] < 0 ? -1 : list.id[j] + id_offset;
     }
   }
 }
@@ -192,6 +225,35 @@ inline int wide_nsplit(int32_t n_a, int32_t n_b) {
 }
 
 }  // namespace
+
+namespace rk {
+
+size_t wide_part_entries(int32_t n_a, int32_t n_b, int32_t K) {
+  return (size_t)n_a * wide_nsplit(n_a, n_b) * kpad_for(K);
+}
+
+int wide_topk(const float *A, int32_t n_a, const float *B, int32_t n_b, int32_t F, const int32_t *mask_ptr,
+              const int32_t *mask_items, int32_t K, int32_t id_offset, float *out_scores, int32_t *out_ids,
+              float *ps, hipStream_t st) {
+  const int kp = kpad_for(K), nsplit = wide_nsplit(n_a, n_b);
+  int32_t *pi = (int32_t *)(ps + (size_t)n_a * nsplit * kp);
+  const int grid = (int)ceil_div(n_a, UPB) * nsplit;
+#define RK_WIDE_CASE(KP)                                                                                           \
+  case KP:                                                                                                         \
+    wide_score_topk_kernel<KP><<<grid, 256, 0, st>>>(A, n_a, B, n_b, F, mask_ptr, mask_items, id_offset, nsplit, ps, pi); \
+    break;
+  switch (kp) {
+    RK_WIDE_CASE(4) RK_WIDE_CASE(8) RK_WIDE_CASE(12) RK_WIDE_CASE(16) RK_WIDE_CASE(20) RK_WIDE_CASE(24) RK_WIDE_CASE(28)
+    default:
+      wide_score_topk_kernel<32><<<grid, 256, 0, st>>>(A, n_a, B, n_b, F, mask_ptr, mask_items, id_offset, nsplit, ps, pi);
+      break;
+  }
+#undef RK_WIDE_CASE
+  RK_CHECK_LAUNCH("wide_score_topk_kernel");
+  return rk_topk_merge_f32(ps, pi, n_a, nsplit, kp, K, out_scores, out_ids, (void *)st);
+}
+
+}  // namespace rk
 
 extern "C" {
 
@@ -211,20 +273,7 @@ int rk_score_topk_wide_f32(const float *A, int32_t n_a, const float *B, int32_t 
   RK_CHECK_ARG(A && B && out_scores && out_ids && ws, "null pointer");
   RK_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "rows must be 16-byte aligned");
   RK_CHECK_ARG(ws_bytes >= rk_score_topk_wide_ws_bytes(n_a, n_b, K), "workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  const int kp = kpad_for(K), nsplit = wide_nsplit(n_a, n_b);
-  float *ps = (float *)ws;
-  int32_t *pi = (int32_t *)(ps + (size_t)n_a * nsplit * kp);
-  const int grid = (int)rk::ceil_div(n_a, UPB) * nsplit;
-#define RK_WIDE_CASE(KP) \
-  case KP: wide_score_topk_kernel<KP><<<grid, 256, 0, st>>>(A, n_a, B, n_b, F, nsplit, ps, pi); break;
-  switch (kp) {
-    RK_WIDE_CASE(4) RK_WIDE_CASE(8) RK_WIDE_CASE(12) RK_WIDE_CASE(16) RK_WIDE_CASE(20) RK_WIDE_CASE(24) RK_WIDE_CASE(28)
-    default: wide_score_topk_kernel<32><<<grid, 256, 0, st>>>(A, n_a, B, n_b, F, nsplit, ps, pi); break;
-  }
-#undef RK_WIDE_CASE
-  RK_CHECK_LAUNCH("wide_score_topk_kernel");
-  return rk_topk_merge_f32(ps, pi, n_a, nsplit, kp, K, out_scores, out_ids, stream);
+  return rk::wide_topk(A, n_a, B, n_b, F, nullptr, nullptr, K, 0, out_scores, out_ids, (float *)ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -125,6 +125,27 @@ def test_filtered_ranking_equals_exact_kernel(U, I, D, K, scale):
     np.testing.assert_array_equal(fs[:64].cpu().numpy(), o_s)
 
 
+@pytest.mark.parametrize("U,I,D,K", [(700, 3000, 256, 20), (130, 517, 192, 32), (65, 129, 320, 5)])
+def test_other_embedding_widths_take_the_chunked_kernel(U, I, D, K):
+    """Widths other than 64 / 128 (the reference's default emb_dim is 256) run the kernel that walks
+    the width in chunks: the same score chain, mask, tie order and id offset, bit for bit the oracle's."""
+    rng = np.random.default_rng(D + U)
+    ue = (np.round(rng.standard_normal((U, D)) * 2) / 2).astype(np.float32)     # many exact ties
+    ie = (np.round(rng.standard_normal((I, D)) * 2) / 2).astype(np.float32)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 30 * U), rng.integers(0, I, 30 * U), U)
+    for mode in ("auto", "exact", "filter"):
+        s, ids = ops.score_topk(dev(ue), dev(ie), K, dev(ptr), dev(mcols), item_id_offset=1000, mode=mode)
+        o_s, o_i = eval_oracle.score_topk(ue, ie, K, ptr, mcols, id_offset=1000)
+        np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
+        np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+    g = torch.Generator().manual_seed(D)
+    uf, itf = torch.randn(U, D, generator=g), torch.randn(I, D, generator=g)
+    s, ids = ops.score_topk(uf.to(DEV), itf.to(DEV), K)
+    o_s, o_i = eval_oracle.score_topk(uf.numpy(), itf.numpy(), K)
+    np.testing.assert_array_equal(ids.cpu().numpy(), o_i)
+    np.testing.assert_array_equal(s.cpu().numpy(), o_s)
+
+
 @pytest.mark.parametrize("dense_users", [40, 3000])
 def test_users_with_long_training_lists_skip_the_filter(dense_users):
     """Users with very long training lists are not masked by the filter pass and are ranked by the
