@@ -5,8 +5,11 @@
 A *step* is one full-ranking evaluation pass over ALL users: fused score + train
 mask + top-20 + the six metrics at k = 5, 10, 20 from embeddings resident in HBM
 (the model forward is timed separately).  `value` = users ranked per second by
-the whole job.  With N > 1 the item table is sharded over the ranks (per-GPU
-top-K, RCCL all-gather, merge): total work is fixed, so scaling is "strong".
+the whole job.  With N > 1 the users are cut into one block per rank, each ranked
+against the whole item table on its GPU (users are independent: only the metric
+sums cross ranks); total work is fixed, so scaling is "strong".  The item-sharded
+form (per-GPU top-K over an item shard, exchange of the lists over RCCL, merge) is
+timed beside it (`item_sharded_eval`), as are the row-sharded hop and training step.
 
 Also reported on the same JSON line: the SpMM hop (algorithmic GB/s against the
 HBM roofline, `roofline_spmm`), the fused top-K call against the MFMA roofline of
@@ -29,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from recommend_amd import ops, synth  # noqa: E402
-from recommend_amd.dist import ShardedRankingEvaluator  # noqa: E402
+from recommend_amd.dist import ShardedRankingEvaluator, UserShardedRankingEvaluator  # noqa: E402
 from recommend_amd.evaluator import RankingEvaluator  # noqa: E402
 from recommend_amd.graph_constructor import GraphConstructor  # noqa: E402
 from recommend_amd.loss import gather_dot_bpr_loss  # noqa: E402
@@ -231,7 +234,9 @@ def main():
 
     # ---------------------------------------------------------------- evaluation (the timed step)
     if world > 1:
-        ev = ShardedRankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, U, I, rank, world)
+        # users are independent units: every rank ranks its block of users against the whole item table,
+        # no candidate lists cross ranks (the item-sharded form is timed further down, beside it)
+        ev = UserShardedRankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, U, I, rank, world)
     else:
         ev = RankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, n_users=U)
     for _ in range(args.warmup):
@@ -257,14 +262,14 @@ def main():
     # dominant kernels of the step: the fused score + mask + top-K launch sequence.  At this size
     # it is the fp16 candidate filter + exact re-scoring (results identical to the exact fp32
     # kernel, which is timed beside it against its own, fp32-input MFMA peak).
-    n_loc = I if world == 1 else (ev.hi - ev.lo)
+    u_loc = U if world == 1 else (ev.u_hi - ev.u_lo)     # this rank's share of the score matrix
     topk_fn = (lambda: ev.topk(ue, ie, 20)) if world == 1 else (lambda: ev.local_topk(ue, ie, 20))
     topk_fn()
     ms_topk = event_ms(topk_fn, max(3, args.steps))
     topk_calls = args.warmup + args.steps + 1 + max(3, args.steps)
-    flop = 2.0 * U * n_loc * D
+    flop = 2.0 * u_loc * I * D
     tflops = flop / (ms_topk * 1e-3) / 1e12
-    filtered = U * n_loc >= (1 << 29) and D in (64, 128)   # what rk_score_topk_f32 decides
+    filtered = u_loc * I >= (1 << 29) and D in (64, 128)   # what rk_score_topk_f32 decides
     peak = MFMA_F16_PEAK_TFS if filtered else MFMA_F32_PEAK_TFS
     traffic_topk, traffic_topk_src = pmc_traffic("score_topk_call", args.shape, D, world)
     roofline = {"kernel": ("score_topk_kernel<fp16 filter> + merge + refine + exact fallback (one rk_score_topk_f32 call)"
@@ -274,7 +279,7 @@ def main():
                 "traffic": traffic_topk, "traffic_source": traffic_topk_src,
                 "traffic_unit": "B per call (L2 memory-side requests, Infinity-Cache hits included)",
                 "ms_per_launch": round(ms_topk, 4),
-                "algorithmic": f"2*U*I*D = {flop:.4g} flop per call",
+                "algorithmic": f"2*U*I*D = {flop:.4g} flop per call" + ("" if world == 1 else " (this rank's users)"),
                 "note": ("peak is the dense fp16 MFMA rate, the arithmetic of the dominant kernel; that kernel is bound "
                          "by the vector instructions of the top-K selection, not by the matrix pipe" if filtered else "")}
     roofline_exact = None
@@ -364,7 +369,33 @@ def main():
             cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \
                                   "oracle's MMFCN at the same shape, no warm-up step"
 
-    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
+    # N > 1: the same evaluation with the ITEMS cut over the ranks instead of the users (per-GPU top-K over
+    # its item shard, exchange of the per-user lists, merge; for item tables too large for one GPU): timed
+    # like the headline step, reported beside it.
+    user_sharded = None
+    if world > 1:
+        try:
+            from recommend_amd.dist import all_reduce_tensor
+            ev_u = ShardedRankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, U, I, rank, world)
+            for _ in range(max(args.warmup, 1)):
+                res_u = ev_u.evaluate(ue, ie)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res_u = ev_u.evaluate(ue, ie)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            all_reduce_tensor(t, dist.ReduceOp.MAX)
+            user_sharded = {"users_per_s": round(U * args.steps / float(t), 1), "ms_per_step": round(1e3 * float(t) / args.steps, 4),
+                            "recall@20": round(float(res_u["recall@20"]), 6),
+                            "layout": f"items in {world} shards, per-GPU top-K, all-to-all of the per-user lists, merge, "
+                                      "all-reduce of the 18 metric sums"}
+        except Exception as e:  # reported, never fatal for the headline line
+            user_sharded = {"error": repr(e)}
+
+    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
     # (a) one propagation hop (all-gather of the layer over RCCL + local SpMM on the rank's rows),
     # (b) the whole MMFCN training step with rows and batch sharded (recommend_amd.dist_train).
     sharded_hop = sharded_train = None
@@ -431,7 +462,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
                                    f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
-                       "parallelism": "single GPU" if world == 1 else f"items sharded over {world} GPUs, exchange of the per-user top-K lists + merge"},
+                       "parallelism": "single GPU" if world == 1 else f"users in {world} blocks (one per GPU) against the whole item table, all-reduce of the metric sums"},
             "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
             "spmm_transpose_ms": round(ms_spmm_t, 5),
             "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
@@ -440,6 +471,8 @@ def main():
         }
         if args.pmc_pass:
             line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
+        if user_sharded is not None:
+            line["item_sharded_eval"] = user_sharded
         if sharded_hop is not None:
             line["row_sharded_hop"] = sharded_hop
         if sharded_train is not None:

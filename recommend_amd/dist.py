@@ -165,6 +165,65 @@ class ShardedRankingEvaluator:
         return out
 
 
+class UserShardedRankingEvaluator:
+    """Full-ranking evaluation with the USERS cut over the ranks: every rank ranks its own block of
+    users against the whole item table (which every rank holds) and only the 18 metric sums cross
+    ranks.  No candidate lists are exchanged or merged and every user is re-scored on one rank
+    only; what it needs instead is the whole item table on every GPU (16 MB at Elec), so it is the
+    form to use when the item table fits one GPU, and the item-sharded evaluator above when it
+    does not.  Same constructor, `evaluate` signature and result as ShardedRankingEvaluator."""
+
+    def __init__(self, target, mask, k_list: Sequence[int], metrics: Sequence[str], n_users: int,
+                 n_items: int, rank: Optional[int] = None, world: Optional[int] = None,
+                 group=None, compute=None):
+        if compute is None:
+            from . import ops as compute  # the HIP path; raises without a GPU
+        self.compute = compute
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.k_list = [int(k) for k in k_list]
+        self.metrics = list(metrics)
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self.u_lo, self.u_hi = user_range(self.n_users, self.rank, self.world)
+        row_id, col_id = mask
+        mp, mc = pairs_to_csr(row_id, col_id, self.n_users)
+        self.mask_ptr = (mp[self.u_lo:self.u_hi + 1] - mp[self.u_lo]).astype(np.int32)
+        self.mask_items = mc[mp[self.u_lo]:mp[self.u_hi]].astype(np.int32)
+        tp, tc = target_to_csr(target, self.n_users)
+        self.tgt_ptr = (tp[self.u_lo:self.u_hi + 1] - tp[self.u_lo]).astype(np.int32)
+        self.tgt_items = tc[tp[self.u_lo]:tp[self.u_hi]].astype(np.int32)
+        self._dev = {}
+
+    _state = ShardedRankingEvaluator._state
+
+    def local_topk(self, user_embeddings, item_embeddings_full, k):
+        """Top-k of this rank's users over all items (global user rows in, local rows out)."""
+        st = self._state(user_embeddings.device)
+        return self.compute.score_topk(_pad64(user_embeddings[self.u_lo:self.u_hi]), _pad64(item_embeddings_full), k,
+                                       st["mask_ptr"], st["mask_items"])
+
+    def evaluate(self, user_embeddings, item_embeddings_full) -> Dict[str, torch.Tensor]:
+        kmax = max(self.k_list)
+        if kmax > self.n_items:
+            raise ValueError("k must be in the range [1, num_items]")
+        st = self._state(user_embeddings.device)
+        sums = torch.zeros((len(self.k_list), 6), dtype=torch.float64, device=user_embeddings.device)
+        self.last_ids = None
+        if self.u_hi > self.u_lo:
+            _s, ids = self.local_topk(user_embeddings, item_embeddings_full, kmax)
+            self.last_ids = ids
+            _out, sums = self.compute.rank_metrics(ids, st["tgt_ptr"], st["tgt_items"], self.k_list,
+                                                   mean_denominator=self.n_users, return_sums=True)
+        all_reduce_tensor(sums, dist.ReduceOp.SUM, self.group)
+        table = (sums / float(self.n_users)).to(torch.float32).cpu()
+        out = {}
+        for ki, k in enumerate(self.k_list):
+            for name in self.metrics:
+                out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
+        return out
+
+
 # --------------------------------------------------------------------------
 # Row-sharded propagation: rank r owns the destination rows [lo_r, hi_r) of the adjacency and the
 # matching rows of every layer's embeddings.  One hop needs every source row, so it is one

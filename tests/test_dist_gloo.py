@@ -70,6 +70,14 @@ def _worker(rank, world, port, q):
         assert (ev.lo, ev.hi) == item_range(I, rank, world)
         res = ev.evaluate(torch.from_numpy(ue), torch.from_numpy(ie))
         ids = ev.last_ids.numpy()
+        # the user-sharded form: same users per rank, no exchange of lists
+        from recommend_amd.dist import UserShardedRankingEvaluator
+        ev2 = UserShardedRankingEvaluator((va[:, 0], va[:, 1]), (tr[:, 0], tr[:, 1]), [5, 10, 20], METRICS,
+                                          U, I, compute=OracleCompute)
+        res2 = ev2.evaluate(torch.from_numpy(ue), torch.from_numpy(ie))
+        assert (ev2.u_lo, ev2.u_hi) == (ev.u_lo, ev.u_hi)
+        assert np.array_equal(ev2.last_ids.numpy(), ids)
+        assert {k: float(v) for k, v in res2.items()} == {k: float(v) for k, v in res.items()}
         q.put((rank, {k: float(v) for k, v in res.items()}, ev.u_lo, ev.u_hi, ids))
     finally:
         dist.destroy_process_group()
