@@ -6,15 +6,16 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import graph_oracle  # noqa: E402
 from recommend_amd import ops, synth  # noqa: E402
 
 shape = sys.argv[1] if len(sys.argv) > 1 else "elec"
 d = synth.make_named(shape)
 tu, ti, tr = d.split(0)
-src, dst, w = graph_oracle.build_coo_vectorized(tu, ti, tr, d.n_users, d.n_items, True)
+src, dst, w = ops.build_coo_host(tu, ti, tr, d.n_users, d.n_items, True)
 N = d.n_users + d.n_items
-wn, _ = graph_oracle.normalize(src, dst, w, N)
+# symmetric normalisation in numpy (a timing input: the values need not be the library's bits)
+root = np.sqrt(np.maximum(np.bincount(dst, weights=w, minlength=N), 1e-12))
+wn = (w / (root[src] * root[dst])).astype(np.float32)
 ptr, idx, eid = ops.csr_from_coo_host(dst.astype(np.int32), src.astype(np.int32), N)
 val = wn[eid].astype(np.float32)
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_variants", f"{shape}_csr.bin")
