@@ -302,7 +302,7 @@ def main():
     traffic_spmm, traffic_spmm_src = pmc_traffic("spmm_hop", args.shape, D, 1)
     spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * D * 4
     gbs = spmm_bytes / (ms_spmm * 1e-3) / 1e9
-    roofline_spmm = {"kernel": "spmm_rows_kernel (+spmm_multi_reduce_kernel)", "bound": "hbm",
+    roofline_spmm = {"kernel": "spmm_rows_kernel (one launch per hop; long rows folded by the last-arriving chunk)", "bound": "hbm",
                      "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": traffic_spmm, "traffic_source": traffic_spmm_src,

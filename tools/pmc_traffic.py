@@ -13,7 +13,7 @@ import sys
 
 src, prefix = sys.argv[1], sys.argv[2]
 
-SPMM = ("spmm_rows_kernel", "spmm_multi_reduce_kernel")
+SPMM = ("spmm_rows_kernel",)
 TOPK = ("score_topk_kernel", "topk_merge_sorted_kernel", "topk_merge_kernel", "refine_kernel", "row_stats_kernel",
         "table_stats_kernel", "to_half_rows_kernel")
 
