@@ -285,6 +285,20 @@ int rk_neg_sample_host(uint32_t *state625_host, const int64_t *users_host,
                        int64_t B, int32_t R, const int32_t *pos_ptr_host,
                        const int32_t *pos_items_host, int32_t n_items,
                        int32_t *rank_out_host, int64_t *neg_out_host);
+/* The same with the emulated candidate orders of some users supplied by the caller:
+ * a user with |pos(u)| >= n_items >> 2 costs a pass over all item ids per sample, and
+ * such users recur in batch after batch.  cached_users: ascending user ids;
+ * cached_order[cached_ptr[i] .. cached_ptr[i+1]) = what rk_neg_order_host writes for
+ * cached_users[i] (n_items - |pos| ids).  Users not in the cache are handled as above;
+ * same random stream, same outputs. */
+int rk_neg_order_host(const int32_t *pos_host, int32_t len, int32_t n_items,
+                      int32_t *order_out_host);
+int rk_neg_sample_cached_host(uint32_t *state625_host, const int64_t *users_host,
+                              int64_t B, int32_t R, const int32_t *pos_ptr_host,
+                              const int32_t *pos_items_host, int32_t n_items,
+                              const int64_t *cached_users_host, const int64_t *cached_ptr_host,
+                              const int32_t *cached_order_host, int32_t n_cached,
+                              int32_t *rank_out_host, int64_t *neg_out_host);
 
 /* ---- L1: BPR gather-dot loss (device) ----------------------------------- */
 /* Replaces GraphTrainer._loss_func, train/graph_trainer.py:255-270, and

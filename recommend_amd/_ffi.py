@@ -87,6 +87,8 @@ SIGNATURES = {
                                         c_size_t, P]),
     "rk_mt_seed_host": (c_int32, [P, c_uint64]),
     "rk_neg_sample_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P]),
+    "rk_neg_order_host": (c_int32, [P, c_int32, c_int32, P]),
+    "rk_neg_sample_cached_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P, P, c_int32, P, P]),
     "rk_bpr_ws_bytes": (c_size_t, [c_int64, c_int32]),
     "rk_bpr_fwd_f32": (c_int32, [P, P, c_int32, P, P, P, c_int64, c_int32, P, P, P, P, c_int32,
                                  P, P, P, c_size_t, P]),

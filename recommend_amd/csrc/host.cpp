@@ -281,12 +281,34 @@ int rk_mt_seed_host(uint32_t *state, uint64_t seed) {
   return RK_OK;
 }
 
+int rk_neg_order_host(const int32_t *pos, int32_t len, int32_t n_items, int32_t *order_out) {
+  RK_CHECK_ARG(len >= 0 && n_items > 0 && len <= n_items && (pos || len == 0) && (order_out || len == n_items),
+               "bad candidate-order arguments");
+  std::vector<int32_t> order;
+  CandidateOrder emu;
+  emu.build(pos, len, n_items, order);
+  if (!order.empty()) memcpy(order_out, order.data(), order.size() * sizeof(int32_t));
+  return RK_OK;
+}
+
 int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
                        int32_t R, const int32_t *pos_ptr,
                        const int32_t *pos_items, int32_t n_items,
                        int32_t *rank_out, int64_t *neg_out) {
+  return rk_neg_sample_cached_host(state, users, B, R, pos_ptr, pos_items, n_items, nullptr, nullptr, nullptr, 0,
+                                   rank_out, neg_out);
+}
+
+int rk_neg_sample_cached_host(uint32_t *state, const int64_t *users, int64_t B,
+                              int32_t R, const int32_t *pos_ptr,
+                              const int32_t *pos_items, int32_t n_items,
+                              const int64_t *cached_users, const int64_t *cached_ptr,
+                              const int32_t *cached_order, int32_t n_cached,
+                              int32_t *rank_out, int64_t *neg_out) {
   RK_CHECK_ARG(state && users && pos_ptr && pos_items, "null input");
   RK_CHECK_ARG(B >= 0 && n_items > 0, "bad sizes");
+  RK_CHECK_ARG(n_cached >= 0 && (n_cached == 0 || (cached_users && cached_ptr && cached_order)),
+               "incomplete candidate-order cache");
   // graph_data_loader.py:365-366
   RK_CHECK_ARG(R > 0, "Negative ratio must be greater than zero");
   // random.sample: setsize = 21; if k > 5: setsize += 4 ** ceil(log(3k, 4))
@@ -319,7 +341,20 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
     }
     // set_difference takes the copy-and-remove path iff (len(all_items) >> 2) > len(pos)
     const bool ascending = (n_items >> 2) > len;
-    if (!ascending) emu.build(pos, len, n_items, order);
+    const int32_t *ord = nullptr;
+    if (!ascending) {
+      // the emulated table costs a pass over all item ids: taken from the caller's cache when
+      // the user is in it (the few users this concerns recur in batch after batch)
+      const int64_t *hit = std::lower_bound(cached_users, cached_users + n_cached, u);
+      if (hit != cached_users + n_cached && *hit == u) {
+        const int64_t at = hit - cached_users;
+        RK_CHECK_ARG(cached_ptr[at + 1] - cached_ptr[at] == n, "cached candidate order has the wrong length");
+        ord = cached_order + cached_ptr[at];
+      } else {
+        emu.build(pos, len, n_items, order);
+        ord = order.data();
+      }
+    }
     // j-th candidate of the reference's list -> item id and its ascending rank
     auto emit = [&](int32_t r, int64_t j) {
       int64_t item, rank;
@@ -327,7 +362,7 @@ int rk_neg_sample_host(uint32_t *state, const int64_t *users, int64_t B,
         rank = j;
         item = kth_missing(pos, len, j);
       } else {
-        item = order[(size_t)j];
+        item = ord[(size_t)j];
         rank = item - (std::lower_bound(pos, pos + len, (int32_t)item) - pos);
       }
       if (rk) rk[r] = (int32_t)rank;

@@ -220,10 +220,8 @@ class TESTModel(nn.Module):
         node_embeddings = self.test(g, self.Xs, [self._first_emb] * self.modal_num, self.ks, self.alphas)
         # dropout(final_projection(.)), Main_Model.py:162-163
         node_embeddings = fused.linear_act(self.final_projection, node_embeddings, None, self.dropout)
-        return {
-            "user_embeddings": node_embeddings[: self.num_users],
-            "item_embeddings": node_embeddings[self.num_users:],
-        }
+        user_embeddings, item_embeddings = ops.split_rows(node_embeddings, self.num_users)
+        return {"user_embeddings": user_embeddings, "item_embeddings": item_embeddings}
 
     def get_model_info(self) -> Dict[str, Any]:
         total_params = sum(p.numel() for p in self.parameters())

@@ -333,12 +333,54 @@ class _Bpr(torch.autograd.Function):
         U, I, users, pos, neg, mask, x, out = ctx.saved_tensors
         B, R, D = ctx.dims
         g = _f32c(g).reshape(1)
-        dU = torch.zeros_like(U)
-        dI = torch.zeros_like(I)
+        if _stacked_rows(U, I):
+            # the two tables are the row blocks of one node matrix (split_rows): their gradients
+            # are written into one matrix, which split_rows' backward hands on as it is
+            both = torch.zeros((U.shape[0] + I.shape[0], D), dtype=torch.float32, device=U.device)
+            dU, dI = both[: U.shape[0]], both[U.shape[0]:]
+        else:
+            dU = torch.zeros_like(U)
+            dI = torch.zeros_like(I)
         _ffi.call("rk_rank_loss_bwd_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg),
                   c_int64(B), c_int32(R), ptr(mask), ptr(x), ptr(out), ptr(g), c_int32(ctx.mode),
                   ptr(dU), ptr(dI), stream_ptr(U.device))
         return dU, dI, None, None, None, None, None, None, None, None, None
+
+
+def _stacked_rows(top, bottom):
+    """True when `top` and `bottom` are the upper and lower row blocks of one contiguous matrix."""
+    return (top.dim() == 2 and bottom.dim() == 2 and top.shape[1] == bottom.shape[1]
+            and top.dtype == bottom.dtype and top.device == bottom.device
+            and top.is_contiguous() and bottom.is_contiguous()
+            and top.untyped_storage().data_ptr() == bottom.untyped_storage().data_ptr()
+            and bottom.storage_offset() == top.storage_offset() + top.numel())
+
+
+class _SplitRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_top):
+        ctx.n_top, ctx.shape = n_top, tuple(x.shape)
+        return x[:n_top], x[n_top:]
+
+    @staticmethod
+    def backward(ctx, g_top, g_bottom):
+        n_top, (n, d) = ctx.n_top, ctx.shape
+        if g_top is not None and g_bottom is not None and _stacked_rows(g_top, g_bottom):
+            return g_top.as_strided((n, d), (d, 1), g_top.storage_offset()), None
+        ref = g_top if g_top is not None else g_bottom
+        if g_top is None:
+            g_top = ref.new_zeros((n_top, d))
+        if g_bottom is None:
+            g_bottom = ref.new_zeros((n - n_top, d))
+        return torch.cat([g_top, g_bottom]), None
+
+
+def split_rows(x, n_top):
+    """(x[:n_top], x[n_top:]) of a node matrix (user rows, item rows: model/Main_Model.py:164-165).  Sliced
+    by autograd each half's gradient becomes a zero-filled copy of the whole matrix and the two are
+    added; here a consumer that wrote both gradients into one matrix (the BPR loss does) passes that
+    matrix on untouched."""
+    return _SplitRows.apply(x, int(n_top))
 
 
 LOSS_BPR, LOSS_LOG_SIGMOID, LOSS_INFO_BPR = 0, 1, 2   # RK_LOSS_* of the header

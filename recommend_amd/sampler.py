@@ -54,6 +54,28 @@ class NegativeSampler:
         self.state = np.zeros(625, np.uint32)
         self.seed(seed)
         self._dev = {}
+        self._cache_orders()
+
+    # candidate-order entries kept for the users whose lists are emulated (1 GiB of ids)
+    CACHE_ENTRIES = 1 << 28
+
+    def _cache_orders(self):
+        """Users holding a quarter of all items or more have their candidates listed in CPython's
+        hash-table order, which costs a pass over every item id to rebuild; there are few of them
+        and they recur in batch after batch, so their orders are built once here."""
+        lens = np.diff(self.pos_ptr.astype(np.int64))
+        heavy = np.flatnonzero((lens >= (self.n_items >> 2)) & (lens < self.n_items))
+        sizes = self.n_items - lens[heavy]
+        keep = np.cumsum(sizes) <= self.CACHE_ENTRIES
+        heavy, sizes = heavy[keep], sizes[keep]
+        self.cached_users = np.ascontiguousarray(heavy, dtype=np.int64)
+        self.cached_ptr = np.zeros(heavy.size + 1, np.int64)
+        np.cumsum(sizes, out=self.cached_ptr[1:])
+        self.cached_order = np.empty(max(int(self.cached_ptr[-1]), 1), np.int32)
+        for i, u in enumerate(heavy):
+            lo, hi = int(self.pos_ptr[u]), int(self.pos_ptr[u + 1])
+            _ffi.call("rk_neg_order_host", ptr(self.pos_items[lo:hi]), c_int32(hi - lo), c_int32(self.n_items),
+                      ptr(self.cached_order[int(self.cached_ptr[i]):int(self.cached_ptr[i + 1])]))
 
     def seed(self, seed):
         """random.seed(seed) for a non-negative int below 2**64."""
@@ -68,9 +90,10 @@ class NegativeSampler:
         B = users.shape[0]
         ranks = np.empty((B, self.neg_ratio), np.int32)
         neg = np.empty((B, self.neg_ratio), np.int64) if want_ids else None
-        _ffi.call("rk_neg_sample_host", ptr(self.state), ptr(users), c_int64(B),
+        _ffi.call("rk_neg_sample_cached_host", ptr(self.state), ptr(users), c_int64(B),
                   c_int32(self.neg_ratio), ptr(self.pos_ptr), ptr(self.pos_items),
-                  c_int32(self.n_items), ptr(ranks), ptr(neg))
+                  c_int32(self.n_items), ptr(self.cached_users), ptr(self.cached_ptr), ptr(self.cached_order),
+                  c_int32(self.cached_users.shape[0]), ptr(ranks), ptr(neg))
         return ranks, neg
 
     def device_csr(self, device):

@@ -159,6 +159,31 @@ def test_backward_with_heavy_collisions_vs_float64_and_bit_reproducible(B, R, D,
             assert torch.equal(gu, grads[0][0]) and torch.equal(gi, grads[0][1])
 
 
+def test_gradient_through_split_rows_equals_separate_tables():
+    """The model hands the loss the two row blocks of one node matrix (ops.split_rows); the loss
+    then writes both gradients into one matrix that reaches the node matrix without a copy.  Same
+    bits as with two separate tables, and the slices autograd would make."""
+    U, I, D, B, R = 300, 500, 64, 2048, 2
+    g = torch.Generator().manual_seed(5)
+    node = torch.randn(U + I, D, generator=g).to(DEV)
+    users = torch.randint(0, U, (B,), generator=g).to(DEV)
+    pos = torch.randint(0, I, (B,), generator=g).to(DEV)
+    neg = torch.randint(0, I, (B, R), generator=g).to(DEV)
+    a = node.clone().requires_grad_(True)
+    ue, ie = ops.split_rows(a * 1.0, U)
+    assert ops._stacked_rows(ue, ie)
+    ops.bpr_gather_dot(ue, ie, users, pos, neg).backward()
+    b = node.clone().requires_grad_(True)
+    h = b * 1.0
+    ops.bpr_gather_dot(h[:U].clone(), h[U:].clone(), users, pos, neg).backward()
+    assert torch.equal(a.grad, b.grad)
+    # only one half used: the other half's gradient is zero
+    c = node.clone().requires_grad_(True)
+    ue, ie = ops.split_rows(c * 1.0, U)
+    (ue * ue).sum().backward()
+    assert torch.equal(c.grad[U:], torch.zeros_like(c.grad[U:])) and torch.allclose(c.grad[:U], 2 * node[:U])
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_loss_variants_vs_reference_and_oracle(golden, name):
     """mmgcn_loss / compute_info_bpr_loss / the SGrec loss on the gather-dot kernels: values

@@ -158,3 +158,75 @@ def test_batches_bit_exact_vs_reference_loader(golden):
             np.testing.assert_array_equal(cat("item_ids"), z[f"{tag}/e{e}/item_ids"])
             np.testing.assert_array_equal(cat("ratings"), z[f"{tag}/e{e}/ratings"])
             np.testing.assert_array_equal(cat("neg_items"), z[f"{tag}/e{e}/neg_items"])
+
+
+def test_split_rows_passes_a_joint_gradient_matrix_through():
+    """ops.split_rows: a consumer that returns the two gradients as the row blocks of one matrix
+    has that matrix handed on as it is; anything else is concatenated (missing halves are zero)."""
+    x = torch.randn(10, 4, requires_grad=True)
+
+    class Joint(torch.autograd.Function):
+        seen = None
+
+        @staticmethod
+        def forward(ctx, a, b):
+            ctx.n = a.shape[0]
+            return a.sum() + 2 * b.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            both = torch.cat([torch.full((ctx.n, 4), 1.0), torch.full((10 - ctx.n, 4), 2.0)])
+            Joint.seen = both
+            return both[: ctx.n], both[ctx.n:]
+
+    top, bottom = ops.split_rows(x, 3)
+    assert ops._stacked_rows(top, bottom) and not ops._stacked_rows(bottom, top)
+    Joint.apply(top, bottom).backward()
+    assert x.grad.data_ptr() == Joint.seen.data_ptr()      # no copy, no add
+    assert torch.equal(x.grad, Joint.seen)
+    x.grad = None
+    top, bottom = ops.split_rows(x, 3)
+    (top.sum() * 3).backward()
+    assert torch.equal(x.grad[:3], torch.full((3, 4), 3.0)) and not x.grad[3:].any()
+    x.grad = None
+    top, bottom = ops.split_rows(x, 3)
+    ((top * top).sum() + (bottom * bottom * bottom).sum()).backward()
+    assert torch.allclose(x.grad[:3], 2 * x.detach()[:3]) and torch.allclose(x.grad[3:], 3 * x.detach()[3:] ** 2)
+
+
+@pytest.mark.parametrize("R", [1, 3, 8])
+def test_cached_candidate_orders_leave_the_sampler_stream_unchanged(R):
+    """Users holding a quarter of the items or more get their candidate list from CPython's set
+    order (emulated); NegativeSampler builds those lists once and hands them to the sampling call.
+    Same ranks, ids and generator state as the call that rebuilds them per sample, and as the
+    oracle's random.sample over list(all_items - pos)."""
+    rng = np.random.default_rng(3)
+    n_items, n_users = 300, 40
+    lens = rng.integers(1, 60, n_users)
+    lens[[3, 11, 29]] = [75, 200, 299]          # 75 = n_items >> 2: the first length that is emulated
+    lens[7] = 74                                # the last one that is not
+    pairs_u = np.concatenate([np.full(l, u) for u, l in enumerate(lens)])
+    pairs_i = np.concatenate([rng.choice(n_items, l, replace=False) for l in lens])
+    # every item id has to occur
+    pairs_u = np.concatenate([pairs_u, np.zeros(n_items, np.int64)])
+    pairs_i = np.concatenate([pairs_i, np.arange(n_items)])
+    ptr_, items_ = build_user_csr(pairs_u, pairs_i, n_users)
+    users = rng.integers(1, n_users, 500).astype(np.int64)   # user 0 holds every item: a separate path
+    users[:6] = [3, 11, 29, 7, 29, 3]
+    s = NegativeSampler(ptr_, items_, n_items, seed=9, neg_ratio=R)
+    assert s.cached_users.tolist() == [3, 11, 29]
+    ranks_c, neg_c = s.sample(users)
+    st = np.zeros(625, np.uint32)
+    _ffi.call("rk_mt_seed_host", _ffi.ptr(st), _ffi.c_uint64(9))
+    ranks_u = np.empty((500, R), np.int32)
+    neg_u = np.empty((500, R), np.int64)
+    _ffi.call("rk_neg_sample_host", _ffi.ptr(st), _ffi.ptr(users), _ffi.c_int64(500), _ffi.c_int32(R), _ffi.ptr(ptr_),
+              _ffi.ptr(items_), _ffi.c_int32(n_items), _ffi.ptr(ranks_u), _ffi.ptr(neg_u))
+    assert np.array_equal(ranks_c, ranks_u) and np.array_equal(neg_c, neg_u) and np.array_equal(s.state, st)
+    random.seed(9)
+    all_items = set(range(n_items))
+    for b, u in enumerate(users[:60]):
+        pos = set(items_[ptr_[u]:ptr_[u + 1]].tolist())
+        cands = list(all_items - pos)
+        want = random.sample(cands, R) if len(cands) >= R else random.choices(cands, k=R)
+        assert neg_c[b].tolist() == want
