@@ -226,6 +226,31 @@ int rk_dense_bwd_accum_f32(const float *X, const float *W, const float *b,
                            int32_t accumulate, void *ws, size_t ws_bytes,
                            void *stream);
 
+/* The backward pass in two halves, for callers that differentiate many layers in a row (one
+ * MGCN branch: 13 calls): rk_dense_bwd_partials_f32 is rk_dense_bwd_f32 without its closing
+ * reduction -- it leaves *n_part_out_host per-workgroup partial sums of dW / db / dalpha in `slab`
+ * (rk_dense_bwd_slab_bytes; K = D = 64 only) -- and rk_dense_reduce_jobs_f32 then reduces any
+ * number of slabs in one launch.  A job lists the slabs whose sums go, added in list order,
+ * to one set of outputs (one slab per application of that weight): the results are bit for
+ * bit those of rk_dense_bwd_f32 / rk_dense_bwd_accum_f32 called layer by layer.  db and dalpha
+ * may be NULL.  jobs_host is a HOST array. */
+#define RK_DENSE_REDUCE_MAX_SLABS 8
+typedef struct rk_dense_reduce_job {
+  const float *slabs[RK_DENSE_REDUCE_MAX_SLABS];
+  int32_t n_slabs;
+  int32_t n_part;          /* partials per slab, as rk_dense_bwd_partials_f32 reported */
+  float *dW, *db, *dalpha;
+} rk_dense_reduce_job;
+size_t rk_dense_bwd_slab_bytes(int64_t n_rows, int32_t K, int32_t D);
+int rk_dense_bwd_partials_f32(const float *X, const float *W, const float *b,
+                              const float *alpha, float p_drop, uint64_t seed,
+                              const uint64_t *seed_step, const float *G,
+                              int64_t n_rows, int32_t K, int32_t D, float *dX,
+                              float *slab, size_t slab_bytes,
+                              int32_t *n_part_out_host, void *stream);
+int rk_dense_reduce_jobs_f32(const rk_dense_reduce_job *jobs_host, int32_t n_jobs,
+                             void *stream);
+
 /* ---- W2: modality-weighted sum (device) ---------------------------------- */
 /* Replaces torch.sum(torch.stack(modal_features) * softmax(alphas)[:, None, None], 0),
  * model/test/out_Layer.py:52-54, and its autograd: out = sum_m softmax(alphas)_m F_m

@@ -51,6 +51,20 @@ class SpmmPlan(Structure):
     ]
 
 
+DENSE_REDUCE_MAX_SLABS = 8
+
+
+class DenseReduceJob(Structure):
+    _fields_ = [
+        ("slabs", c_void_p * DENSE_REDUCE_MAX_SLABS),
+        ("n_slabs", c_int32),
+        ("n_part", c_int32),
+        ("dW", c_void_p),
+        ("db", c_void_p),
+        ("dalpha", c_void_p),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); mirrors include/recommend_amd.h declaration by declaration
 SIGNATURES = {
@@ -79,6 +93,10 @@ SIGNATURES = {
                                    P, P, P, P, P, c_size_t, P]),
     "rk_dense_bwd_accum_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
                                          P, P, P, P, c_int32, P, c_size_t, P]),
+    "rk_dense_bwd_slab_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "rk_dense_bwd_partials_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
+                                            P, P, c_size_t, POINTER(c_int32), P]),
+    "rk_dense_reduce_jobs_f32": (c_int32, [P, c_int32, P]),
     "rk_modal_sum_fwd_f32": (c_int32, [P, c_int32, P, c_int64, P, P]),
     "rk_modal_sum_bwd_ws_bytes": (c_size_t, []),
     "rk_modal_sum_bwd_f32": (c_int32, [P, P, c_int32, P, P, c_int64, P, P, c_size_t, P]),
@@ -182,6 +200,6 @@ def stream_ptr(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-__all__ = ["load", "call", "check", "ptr", "stream_ptr", "SpmmPlan", "RkError", "SIGNATURES",
+__all__ = ["load", "call", "check", "ptr", "stream_ptr", "SpmmPlan", "DenseReduceJob", "RkError", "SIGNATURES",
            "LIB_PATH", "device_count", "require_device", "last_error",
            "c_int32", "c_int64", "c_float", "c_double", "c_uint32", "c_size_t"]

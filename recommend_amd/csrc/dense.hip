@@ -23,6 +23,8 @@
 // C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  The reduction index is walked so that a
 // lane's operand values are contiguous in its row: A and B only have to agree on
 // which index a lane's j-th value of a step stands for.
+#include <string.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -721,6 +723,50 @@ __global__ __launch_bounds__(256) void dense_reduce_kernel(const float *__restri
     dalpha[0] = accumulate ? dalpha[0] + s : s;
 }
 
+// The same reduction for several layers in one launch (blockIdx.y = job): a backward pass with a
+// dozen layer calls otherwise spends a launch of a few microseconds of work after each.  A job
+// that lists several slabs (one weight applied several times) adds their sums in list order,
+// with the operations the accumulate form of the kernel above would have performed call by call.
+constexpr int kJobsPerLaunch = 16;
+struct ReduceJobs {
+  rk_dense_reduce_job job[kJobsPerLaunch];
+};
+__global__ __launch_bounds__(256) void dense_reduce_jobs_kernel(ReduceJobs jobs) {
+  __shared__ float red[16][17];
+  const rk_dense_reduce_job &jb = jobs.job[blockIdx.y];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
+  float total = 0.0f;
+  for (int32_t sl = 0; sl < jb.n_slabs; ++sl) {      // uniform over the workgroup
+    const float *__restrict__ slab = jb.slabs[sl];
+    float s0 = 0.0f, s1 = 0.0f;
+    if (i < NRED) {
+      int32_t p = q;
+      for (; p + 16 < jb.n_part; p += 32) {
+        s0 += slab[(int64_t)p * PART + i];
+        s1 += slab[(int64_t)(p + 16) * PART + i];
+      }
+      if (p < jb.n_part) s0 += slab[(int64_t)p * PART + i];
+    }
+    __syncthreads();                                 // the previous slab's fold has been read
+    red[q][el] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[k][el];
+      total = sl == 0 ? s : total + s;
+    }
+  }
+  if (q != 0 || i >= NRED) return;
+  if (i < DD * DD)
+    jb.dW[i] = total;
+  else if (i < DD * DD + DD) {
+    if (jb.db) jb.db[i - DD * DD] = total;
+  } else if (jb.dalpha)
+    jb.dalpha[0] = total;
+}
+
 inline int cu_count() {
   static int cached = 0;
   if (cached == 0) {
@@ -798,6 +844,52 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
                      float *dW, float *db, float *dalpha, void *ws, size_t ws_bytes, void *stream) {
   return rk_dense_bwd_accum_f32(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, K, D, dX, dW, db, dalpha, 0, ws,
                                 ws_bytes, stream);
+}
+
+size_t rk_dense_bwd_slab_bytes(int64_t n_rows, int32_t K, int32_t D) {
+  if (n_rows <= 0 || K != DD || D != DD) return 0;
+  return (size_t)kBwdMaxGrid * PART * sizeof(float);
+}
+
+int rk_dense_bwd_partials_f32(const float *X, const float *W, const float *b, const float *alpha, float p_drop,
+                              uint64_t seed, const uint64_t *seed_step, const float *G, int64_t n_rows, int32_t K,
+                              int32_t D, float *dX, float *slab, size_t slab_bytes, int32_t *n_part_out, void *stream) {
+  RK_CHECK_ARG(n_rows > 0, "empty layer input");
+  if (K != DD || D != DD)
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_partials_f32: built for 64 -> 64 layers (got %d -> %d)", K, D);
+  RK_CHECK_ARG(X && W && G && slab && n_part_out, "null pointer");
+  RK_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "dropout probability must be in [0, 1)");
+  RK_CHECK_ARG(slab_bytes >= rk_dense_bwd_slab_bytes(n_rows, K, D), "slab too small");
+  RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(G) && rk::aligned16(dX) && rk::aligned16(slab),
+               "matrices must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = bwd_grid(n_rows);
+  if (alpha)
+    dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, slab);
+  else
+    dense_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX, slab);
+  RK_CHECK_LAUNCH("dense_bwd_kernel");
+  *n_part_out = grid;
+  return RK_OK;
+}
+
+int rk_dense_reduce_jobs_f32(const rk_dense_reduce_job *jobs, int32_t n_jobs, void *stream) {
+  RK_CHECK_ARG(n_jobs >= 0 && (jobs || n_jobs == 0), "bad job list");
+  for (int32_t j = 0; j < n_jobs; ++j) {
+    RK_CHECK_ARG(jobs[j].n_slabs >= 1 && jobs[j].n_slabs <= RK_DENSE_REDUCE_MAX_SLABS, "a job lists 1..RK_DENSE_REDUCE_MAX_SLABS slabs");
+    RK_CHECK_ARG(jobs[j].n_part >= 1 && jobs[j].n_part <= kBwdMaxGrid && jobs[j].dW, "bad job");
+    for (int32_t sl = 0; sl < jobs[j].n_slabs; ++sl) RK_CHECK_ARG(jobs[j].slabs[sl], "null slab");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int32_t j0 = 0; j0 < n_jobs; j0 += kJobsPerLaunch) {
+    const int32_t nj = std::min<int32_t>(kJobsPerLaunch, n_jobs - j0);
+    ReduceJobs args;
+    memset(&args, 0, sizeof args);
+    for (int32_t j = 0; j < nj; ++j) args.job[j] = jobs[j0 + j];
+    dense_reduce_jobs_kernel<<<dim3((NRED + 15) / 16, nj), 256, 0, st>>>(args);
+    RK_CHECK_LAUNCH("dense_reduce_jobs_kernel");
+  }
+  return RK_OK;
 }
 
 int rk_dense_bwd_accum_f32(const float *X, const float *W, const float *b, const float *alpha, float p_drop,

@@ -6,7 +6,7 @@ Composed from per-layer autograd nodes the branch costs, per training step, one 
 every extra use of a tensor (the aggregation's Linear is applied k times, the projected features
 X feed the aggregation and every Combine layer) -- the largest of them over N x D matrices.  Here
 the backward pass is written out: the weight gradients of the k applications accumulate inside
-the layer kernel's reduction, and the gradient of X is one launch of the two-input layer kernel,
+the layer kernel's reduction (one launch for the reductions of all the branch's layer calls), and the gradient of X is one launch of the two-input layer kernel,
     dX = gY_0 W_ori,0 + gY_1 W_ori,1 + dX_aggregation
 (the forward kernel with the transposed weights and the aggregation's gradient as its residual).
 
@@ -59,19 +59,21 @@ class _MGCN(torch.autograd.Function):
         need_X, need_emb = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = ops._f32c(g)
         n, D = X.shape
-        ws = ops.dense_bwd_ws(n, D, D, g.device)
+        # the closing reductions of the 13 layer calls below run as one launch at the end
+        rq = ops.DenseReduceQueue(n, D, g.device)
+        ws = None if rq.usable else ops.dense_bwd_ws(n, D, D, g.device)
 
         # out = a_L + dropout(prelu(W_m emb + b_m)): the residual passes g through
-        d_emb, dWm, dbm, dam = ops.dense_bwd_raw(emb, Wm, bm, am, p_out, seeds[k + L], g, need_emb, True, None, ws)
+        d_emb, dWm, dbm, dam = ops.dense_bwd_raw(emb, Wm, bm, am, p_out, seeds[k + L], g, need_emb, True, None, ws, rq)
         g_a = g
         comb_grads = [None] * L
         g_ys = [None] * L
         for l in reversed(range(L)):
             W_ori, b_ori, W_f, b_f, W_o, b_o, al = comb[l]
-            g_y, dW_o, db_o, dal = ops.dense_bwd_raw(ys[l], W_o, b_o, al, p_comb[l], seeds[k + l], g_a, True, True, None, ws)
+            g_y, dW_o, db_o, dal = ops.dense_bwd_raw(ys[l], W_o, b_o, al, p_comb[l], seeds[k + l], g_a, True, True, None, ws, rq)
             # y = X W_ori^T + a W_f^T + b_ori + b_f: both biases get the column sums of g_y
-            _, dW_ori, db_lin, _ = ops.dense_bwd_raw(X, W_ori, None, None, 0.0, 0, g_y, False, True, None, ws)
-            g_a, dW_f, _, _ = ops.dense_bwd_raw(a_in[l], W_f, None, None, 0.0, 0, g_y, True, False, None, ws)
+            _, dW_ori, db_lin, _ = ops.dense_bwd_raw(X, W_ori, None, None, 0.0, 0, g_y, False, True, None, ws, rq)
+            g_a, dW_f, _, _ = ops.dense_bwd_raw(a_in[l], W_f, None, None, 0.0, 0, g_y, True, False, None, ws, rq)
             g_ys[l] = g_y
             comb_grads[l] = [dW_ori, db_lin if b_ori is not None else None, dW_f, db_lin if b_f is not None else None,
                              dW_o, db_o if b_o is not None else None, dal]
@@ -80,7 +82,7 @@ class _MGCN(torch.autograd.Function):
         agg = None
         for t in reversed(range(k)):
             g_z = hops.backward(g_h)
-            g_h, dWa, dba, daa = ops.dense_bwd_raw(hs[t], Wa, ba, aa, p_agg, seeds[t], g_z, t > 0 or need_X, True, agg, ws)
+            g_h, dWa, dba, daa = ops.dense_bwd_raw(hs[t], Wa, ba, aa, p_agg, seeds[t], g_z, t > 0 or need_X, True, agg, ws, rq)
             agg = (dWa, dba, daa)
         dX = None
         if need_X:
@@ -94,6 +96,7 @@ class _MGCN(torch.autograd.Function):
                 else:
                     dX = ops.dense_fwd_raw(g_ys[l], comb[l][0].t().contiguous(), None, residual=dX)
                     l += 1
+        rq.flush()
         grads = [agg[0], agg[1] if ba is not None else None, agg[2]]
         for cg in comb_grads:
             grads += cg

@@ -458,17 +458,63 @@ def dense_bwd_ws(n, K, D, device):
     return torch.empty(_ffi.load().rk_dense_bwd_ws_bytes(n, K, D) // 4 + 4, dtype=torch.float32, device=device)
 
 
-def dense_bwd_raw(x, w, b, alpha, p, seed, g, want_dx=True, want_db=True, grads=None, ws=None):
+class DenseReduceQueue:
+    """The closing reductions of several dense_bwd_raw calls, run as one launch by flush().
+
+    A call with `defer=queue` leaves its per-workgroup partial sums in a slab of its own and
+    returns dW / db / dalpha tensors that hold their values only after flush(); calls that add to
+    the same tensors (grads=...) become one job whose slabs are summed in call order -- the bits
+    are those of the immediate calls.  Built for the 64-wide layers; other widths reduce at once."""
+
+    def __init__(self, n_rows, width, device):
+        self.n_rows, self.width, self.device = int(n_rows), int(width), device
+        self.slab_floats = _ffi.load().rk_dense_bwd_slab_bytes(self.n_rows, self.width, self.width) // 4
+        self.jobs = []       # [dw, db, da, n_part, [slabs]]
+
+    @property
+    def usable(self):
+        return self.slab_floats > 0
+
+    def new_slab(self):
+        return torch.empty(self.slab_floats, dtype=torch.float32, device=self.device)
+
+    def add(self, slab, n_part, dw, db, da, accumulate):
+        if accumulate:
+            for job in self.jobs:
+                if job[0] is dw:
+                    if job[3] != n_part or len(job[4]) >= _ffi.DENSE_REDUCE_MAX_SLABS:
+                        break
+                    job[4].append(slab)
+                    return
+            raise ValueError("deferred accumulation needs the call that created these gradient tensors in the "
+                             f"same queue, and at most {_ffi.DENSE_REDUCE_MAX_SLABS} calls per tensor")
+        self.jobs.append([dw, db, da, n_part, [slab]])
+
+    def flush(self):
+        if not self.jobs:
+            return
+        arr = (_ffi.DenseReduceJob * len(self.jobs))()
+        for j, (dw, db, da, n_part, slabs) in enumerate(self.jobs):
+            for i, sl in enumerate(slabs):
+                arr[j].slabs[i] = sl.data_ptr()
+            arr[j].n_slabs, arr[j].n_part = len(slabs), n_part
+            arr[j].dW = dw.data_ptr()
+            arr[j].db = db.data_ptr() if db is not None else None
+            arr[j].dalpha = da.data_ptr() if da is not None else None
+        _ffi.call("rk_dense_reduce_jobs_f32", arr, c_int32(len(self.jobs)), stream_ptr(self.device))
+        self.jobs = []
+
+
+def dense_bwd_raw(x, w, b, alpha, p, seed, g, want_dx=True, want_db=True, grads=None, ws=None, defer=None):
     """Backward of the single-input layer for upstream gradient g -> (dX or None, dW, db or None,
     dalpha or None).  grads = (dW, db, dalpha) buffers to ADD the weight gradients to (a layer
     applied several times); otherwise fresh tensors are written.  The dropout step counter
-    registered for the device is mixed into the seed exactly as the forward call did."""
+    registered for the device is mixed into the seed exactly as the forward call did.
+    defer: a DenseReduceQueue that runs this call's closing reduction later (see there)."""
     _need_cuda(x, w, b, alpha, g)
     n, K = x.shape
     D = w.shape[0]
     dev = g.device
-    if ws is None:
-        ws = dense_bwd_ws(n, K, D, dev)
     dx = torch.empty_like(x) if want_dx else None
     acc = grads is not None
     if acc:
@@ -478,6 +524,16 @@ def dense_bwd_raw(x, w, b, alpha, p, seed, g, want_dx=True, want_db=True, grads=
         db = torch.empty(D, dtype=torch.float32, device=dev) if want_db else None
         da = torch.empty(1, dtype=torch.float32, device=dev) if alpha is not None else None
     step = _dropout_step.get(dev) if p > 0.0 else None
+    if defer is not None and defer.usable and K == defer.width and D == defer.width and n == defer.n_rows:
+        slab = defer.new_slab()
+        n_part = c_int32(0)
+        _ffi.call("rk_dense_bwd_partials_f32", ptr(x), ptr(w), ptr(b), ptr(alpha), c_float(p), _ffi.c_uint64(seed),
+                  ptr(step), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(slab),
+                  c_size_t(slab.numel() * 4), ctypes.byref(n_part), stream_ptr(dev))
+        defer.add(slab, n_part.value, dw, db, da, acc)
+        return dx, dw, db, da
+    if ws is None:
+        ws = dense_bwd_ws(n, K, D, dev)
     _ffi.call("rk_dense_bwd_accum_f32", ptr(x), ptr(w), ptr(b), ptr(alpha), c_float(p), _ffi.c_uint64(seed),
               ptr(step), ptr(g), c_int64(n), c_int32(K), c_int32(D), ptr(dx), ptr(dw), ptr(db), ptr(da),
               c_int32(1 if acc else 0), ptr(ws), c_size_t(ws.numel() * 4), stream_ptr(dev))

@@ -180,3 +180,47 @@ def test_dense_products_keep_fp32_accuracy_over_the_exponent_range():
     assert float(((xd.grad.cpu().double() - g6 @ w6).abs() / bound_dx).max()) <= 1e-6
     bound_dw = g6.abs().T @ x6.abs()
     assert float(((wd.grad.cpu().double() - g6.T @ x6).abs() / bound_dw).max()) <= 1e-6
+
+
+@pytest.mark.parametrize("n", [5000, 70001])
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(n):
+    """ops.DenseReduceQueue: the closing reductions of several layer backward calls as one launch,
+    among them one weight applied three times (its slabs are added in call order).  Every output
+    bit for bit what the calls produce when each reduces at once."""
+    g = torch.Generator().manual_seed(n)
+    D = 64
+    xs = [torch.randn(n, D, generator=g).to(DEV) for _ in range(5)]
+    gs = [torch.randn(n, D, generator=g).to(DEV) for _ in range(5)]
+    ws_ = [(torch.randn(D, D, generator=g) * 0.2).to(DEV) for _ in range(3)]
+    b = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    al = torch.tensor([0.25], device=DEV)
+
+    def run(queue):
+        outs = []
+        # one weight, three applications, gradients accumulated
+        acc = None
+        for t in range(3):
+            dx, dw, db, da = ops.dense_bwd_raw(xs[t], ws_[0], b, al, 0.3, 77 + t, gs[t], True, True, acc, None, queue)
+            acc = (dw, db, da)
+            outs.append(dx)
+        outs += list(acc)
+        # a linear layer without bias gradient or input gradient, and one without activation
+        dx, dw, db, da = ops.dense_bwd_raw(xs[3], ws_[1], None, None, 0.0, 0, gs[3], False, False, None, None, queue)
+        assert dx is None and db is None and da is None
+        outs.append(dw)
+        dx, dw, db, da = ops.dense_bwd_raw(xs[4], ws_[2], b, None, 0.0, 0, gs[4], True, True, None, None, queue)
+        outs += [dx, dw, db]
+        if queue is not None:
+            queue.flush()
+        return outs
+
+    want = run(None)
+    q = ops.DenseReduceQueue(n, D, torch.device(DEV))
+    assert q.usable
+    got = run(q)
+    assert not q.jobs
+    for a, e in zip(got, want):
+        assert torch.equal(a, e)
+    # a width the deferred form is not built for reduces at once
+    q128 = ops.DenseReduceQueue(1000, 128, torch.device(DEV))
+    assert not q128.usable
