@@ -373,6 +373,52 @@ def main():
     # its item shard, exchange of the per-user lists, merge; for item tables too large for one GPU): timed
     # like the headline step, reported beside it.
     user_sharded = None
+    sharded_hop = sharded_train = None
+
+    def emit():
+        if rank == 0:
+            line = {
+                "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
+                "value": round(users_per_s, 1), "unit": "users/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+                "dtype": "f32 (results; candidates by fp16 MFMA, certified against the fp32 chain)",
+                "data": "synthetic",
+                "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
+                                       f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
+                           "parallelism": "single GPU" if world == 1 else f"users in {world} blocks (one per GPU) against the whole item table, all-reduce of the metric sums"},
+                "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
+                "spmm_transpose_ms": round(ms_spmm_t, 5),
+                "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
+                "recall@20": round(float(res["recall@20"]), 6),
+                "kernel_source_digest": kernel_source_digest(),
+            }
+            if args.pmc_pass:
+                line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
+            if world > 1:
+                line["item_sharded_eval"] = user_sharded
+                line["row_sharded_hop"] = sharded_hop
+                line["row_sharded_train_step"] = sharded_train
+            print(json.dumps(line), flush=True)
+
+    # The legs below are reported beside the headline and run after it.  They contain collectives; should
+    # one of them never return (they have run over gloo only), every rank gives up after a while and rank 0
+    # prints the line with what has been measured.
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def give_up():
+            nonlocal user_sharded, sharded_hop, sharded_train
+            note = {"error": "did not finish within the leg's time limit"}
+            user_sharded = user_sharded or note
+            sharded_hop = sharded_hop or note
+            sharded_train = sharded_train or note
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("BENCH_LEG_LIMIT_S", "420")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if world > 1:
         try:
             from recommend_amd.dist import all_reduce_tensor
@@ -395,10 +441,9 @@ def main():
         except Exception as e:  # reported, never fatal for the headline line
             user_sharded = {"error": repr(e)}
 
-    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
+    # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
     # (a) one propagation hop (all-gather of the layer over RCCL + local SpMM on the rank's rows),
     # (b) the whole MMFCN training step with rows and batch sharded (recommend_amd.dist_train).
-    sharded_hop = sharded_train = None
     if world > 1:
         from recommend_amd.dist import RowShardedGraph, all_reduce_tensor
         try:
@@ -452,32 +497,9 @@ def main():
                                        "eager launches (no captured graph: the step contains collectives)"}
         except Exception as e:
             sharded_train = {"error": repr(e)}
-    if rank == 0:
-        line = {
-            "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
-            "value": round(users_per_s, 1), "unit": "users/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f32 (results; candidates by fp16 MFMA, certified against the fp32 chain)",
-            "data": "synthetic",
-            "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
-                                   f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
-                       "parallelism": "single GPU" if world == 1 else f"users in {world} blocks (one per GPU) against the whole item table, all-reduce of the metric sums"},
-            "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
-            "spmm_transpose_ms": round(ms_spmm_t, 5),
-            "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
-            "recall@20": round(float(res["recall@20"]), 6),
-            "kernel_source_digest": kernel_source_digest(),
-        }
-        if args.pmc_pass:
-            line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
-        if user_sharded is not None:
-            line["item_sharded_eval"] = user_sharded
-        if sharded_hop is not None:
-            line["row_sharded_hop"] = sharded_hop
-        if sharded_train is not None:
-            line["row_sharded_train_step"] = sharded_train
-        print(json.dumps(line), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 
