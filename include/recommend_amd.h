@@ -419,7 +419,10 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * Ranking: score descending, ties by lower item id.  mask_ptr/mask_items: CSR of
  * the training interactions per user (items ascending, local to this item
  * range), may be NULL.  Item ids written are local index + item_id_offset.
- * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 32).
+ * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 128).  K <= 32 is one
+ * per-lane list; a longer ranking (D = 64 or 128 only) is produced 32 places at a time by the
+ * exact kernel, every page restricted to the items that rank strictly after the last entry
+ * of the page before (one pass over the items per page).
  *
  * All three entry points return the same bits; they differ in how they get there.
  * rk_score_topk_exact_f32 ranks every score on the exact kernel (D = 64 or 128: user rows resident
@@ -466,7 +469,8 @@ int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users,
 /* Replaces torch.topk(scores, k, dim=1, largest=True, sorted=True) of
  * evaluate_all_at_k, evalue/metric.py:114, for callers that hand over the dense
  * scores[n_rows, n_items] (row stride ld floats).  Ranking: score descending, ties by
- * lower column id.  out_scores/out_ids: n_rows x K.  1 <= K <= min(n_items, 32). */
+ * lower column id.  out_scores/out_ids: n_rows x K.  1 <= K <= min(n_items, 128) (above 32: pages
+ * of 32 places, one scan of the scores per page). */
 size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K);
 int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items,
                      int64_t ld, int32_t K, float *out_scores, int32_t *out_ids,
@@ -490,7 +494,8 @@ int rk_score_topk_wide_f32(const float *A, int32_t n_a, const float *B,
 /* ---- M: ranking metrics (device) ---------------------------------------- */
 /* Replaces evaluate_all_at_k, evalue/metric.py:106-164, for every k in k_list
  * at once from one sorted top-Kmax id list per user and the CSR of the target
- * (validation/test) items per user (sorted).  discounts[j] = 1/log2(j+2).
+ * (validation/test) items per user (sorted).  discounts[j] = 1/log2(j+2).  Up to 8 values of k,
+ * each in [1, min(128, id_stride)].
  * out[ki*6 + m], m = precision, recall, hit_rate, ndcg, map, mrr: means over
  * all n_users rows.  sums_out (may be NULL): the same as double sums before
  * the division (for cross-GPU reduction).  ws: rk_rank_metrics_ws_bytes(). */

@@ -32,19 +32,32 @@ namespace {
 // reads) into its own sorted list; the 32 lists of a row are merged by topk_merge_kernel.
 constexpr int ROWS_LANES = 32;
 
-template <int KPAD>
+// CEIL: a later page of a ranking longer than one list (see score_topk_kernel): only columns that
+// rank strictly after (ceil_s[row], ceil_id[row]) take part.
+template <int KPAD, bool CEIL = false>
 __global__ __launch_bounds__(256) void rows_topk_kernel(const float *__restrict__ scores, int32_t n_rows,
                                                         int32_t n_items, int64_t ld,
                                                         float *__restrict__ part_s,
-                                                        int32_t *__restrict__ part_id) {
+                                                        int32_t *__restrict__ part_id,
+                                                        const float *__restrict__ ceil_s = nullptr,
+                                                        const int32_t *__restrict__ ceil_id = nullptr) {
   const int sub = threadIdx.x % ROWS_LANES;
   const int32_t row = blockIdx.x * (256 / ROWS_LANES) + threadIdx.x / ROWS_LANES;
   if (row >= n_rows) return;
   LaneList<KPAD> list;
   list.init();
   const float *src = scores + (int64_t)row * ld;
+  float page_s = INFINITY;
+  int32_t page_id = -1;
+  if constexpr (CEIL) {
+    page_s = ceil_s[row];
+    page_id = ceil_id[row];
+  }
   for (int32_t i = sub; i < n_items; i += ROWS_LANES) {
     const float v = src[i];
+    if constexpr (CEIL) {
+      if (v > page_s || (v == page_s && i <= page_id)) continue;
+    }
     if (v > list.s[KPAD - 1]) list.insert(v, i);   // ascending ids + strict '>' keep lower ids first
   }
   const int64_t base = ((int64_t)row * ROWS_LANES + sub) * KPAD;
@@ -185,6 +198,31 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
   }
 }
 
+// Rankings longer than one list (32 < K <= kMaxK) are produced a page of kPage places at a time:
+// page p is the kPage best among the items that rank strictly after the last entry of page p - 1.
+// This kernel files a finished page (n_rows x kPage, local ids) under columns col0.. of the
+// K-wide outputs and records every row's last entry as the ceiling of the next page (a page
+// that is not full has exhausted its row: nothing ranks after (-inf, INT32_MAX)).
+constexpr int kPage = 32, kMaxK = 128;
+__global__ __launch_bounds__(256) void place_page_kernel(const float *__restrict__ page_s, const int32_t *__restrict__ page_id,
+                                                         int32_t n_rows, int32_t K, int32_t col0, int32_t id_offset,
+                                                         float *__restrict__ out_s, int32_t *__restrict__ out_id,
+                                                         float *__restrict__ ceil_s, int32_t *__restrict__ ceil_id) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t row = (int32_t)(t / kPage), j = (int32_t)(t % kPage);
+  if (row >= n_rows) return;
+  const float v = page_s[t];
+  const int32_t id = page_id[t];
+  if (col0 + j < K) {
+    out_s[(int64_t)row * K + col0 + j] = id >= 0 ? v : -INFINITY;
+    out_id[(int64_t)row * K + col0 + j] = id >= 0 ? id + id_offset : -1;
+  }
+  if (j == kPage - 1) {
+    ceil_s[row] = id >= 0 ? v : -INFINITY;
+    ceil_id[row] = id >= 0 ? id : INT32_MAX;
+  }
+}
+
 // ---------------------------------------------------------------- M -------
 constexpr int MAXK = 8;  // k values per call
 
@@ -192,6 +230,8 @@ struct KList {
   int32_t k[MAXK];
 };
 
+// NW: ranking places in units of 32 (1 for k <= 32; 4 for rankings of up to kMaxK places)
+template <int NW>
 __global__ __launch_bounds__(256) void rank_metrics_kernel(
     const int32_t *__restrict__ topk_ids, int32_t n_users, int32_t id_stride,
     const int32_t *__restrict__ tgt_ptr, const int32_t *__restrict__ tgt_items,
@@ -205,19 +245,22 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
   if (u < n_users) {
     const int32_t tb = tgt_ptr[u], te = tgt_ptr[u + 1];
     const int32_t n_pos = te - tb;
-    uint32_t rel = 0;  // bit j: j-th ranked item is a target item
+    constexpr int NR = 32 * NW;
+    uint32_t rel[NW];  // bit j: j-th ranked item is a target item
+#pragma unroll
+    for (int w = 0; w < NW; ++w) rel[w] = 0;
     // The ranked ids go to registers with independent loads.  A user with a handful of target
     // items compares each of them with all ranked ids (a bisection per ranked item is a chain of
     // dependent loads four deep, kmax times over); the few users with long target lists bisect (a
     // walk over thousands of targets is thousands of dependent loads in one lane: 2.5 ms at Elec).
-    int32_t ranked[32];
+    int32_t ranked[NR];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) ranked[j] = j < kmax ? topk_ids[(int64_t)u * id_stride + j] : -1;
+    for (int j = 0; j < NR; ++j) ranked[j] = j < kmax ? topk_ids[(int64_t)u * id_stride + j] : -1;
     if (n_pos <= 16) {
       for (int32_t t = tb; t < te; ++t) {
         const int32_t v = tgt_items[t];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) rel |= (ranked[j] == v && v >= 0 ? 1u : 0u) << j;
+        for (int j = 0; j < NR; ++j) rel[j >> 5] |= (ranked[j] == v && v >= 0 ? 1u : 0u) << (j & 31);
       }
     } else {
       // long target lists (sorted): a bisection per ranked item
@@ -225,7 +268,7 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
       for (int j = 0; j < kmax; ++j) {
         int32_t it = ranked[0];
 #pragma unroll
-        for (int q = 1; q < 32; ++q) it = q == j ? ranked[q] : it;   // (no indexed access: the ids stay in registers)
+        for (int q = 1; q < NR; ++q) it = q == j ? ranked[q] : it;   // (no indexed access: the ids stay in registers)
         int32_t lo = tb, hi = te;
         while (lo < hi) {
           const int32_t mid = (lo + hi) >> 1;
@@ -234,7 +277,10 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
           else
             hi = mid;
         }
-        if (it >= 0 && lo < te && tgt_items[lo] == it) rel |= 1u << j;
+        if (it >= 0 && lo < te && tgt_items[lo] == it) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) rel[w] |= (w == (j >> 5) ? 1u : 0u) << (j & 31);
+        }
       }
     }
     // evalue/metric.py:119-155, per user, fp32
@@ -247,7 +293,10 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
         int first = 0;
         const int ideal_k = min(n_pos, k);
         for (int j = 0; j < k; ++j) {
-          const float rj = (float)((rel >> j) & 1u);
+          uint32_t word = rel[0];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) word = w == (j >> 5) ? rel[w] : word;
+          const float rj = (float)((word >> (j & 31)) & 1u);
           hits += rj;
           dcg += rj * disc[j];
           if (j < ideal_k) idcg += disc[j];
@@ -311,7 +360,30 @@ int launch_score_topk(int DC, int grid, hipStream_t st, const float *Uemb, int32
                       const float *Iemb, int32_t n_items, const int32_t *mask_ptr,
                       const int32_t *mask_items, int32_t nsplit, int32_t off, const int32_t *skip,
                       const int32_t *user_list, const int32_t *user_count, int32_t gate_cap, float *ps,
-                      int32_t *pi) {
+                      int32_t *pi, const float *ceil_s = nullptr, const int32_t *ceil_id = nullptr) {
+  if (ceil_s != nullptr) {
+    // a later page of a long ranking: full-length lists, all users
+    if constexpr (KPAD == kPage) {
+      switch (DC) {
+        case 1:
+          score_topk_kernel<KPAD, 1, false, true><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr, mask_items,
+                                                                        nsplit, off, skip, user_list, user_count, gate_cap,
+                                                                        ps, pi, nullptr, ceil_s, ceil_id);
+          break;
+        case 2:
+          score_topk_kernel<KPAD, 2, false, true><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr, mask_items,
+                                                                        nsplit, off, skip, user_list, user_count, gate_cap,
+                                                                        ps, pi, nullptr, ceil_s, ceil_id);
+          break;
+        default:
+          return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: embedding width %d not built (64/128)", 64 * DC);
+      }
+      RK_CHECK_LAUNCH("score_topk_kernel");
+      return RK_OK;
+    } else {
+      return rk::fail(RK_ERR_ARG, "pages are ranked with full-length lists");
+    }
+  }
   switch (DC) {
     case 1:
       score_topk_kernel<KPAD, 1, false><<<grid, 256, 0, st>>>(Uemb, n_users, Iemb, n_items, mask_ptr,
@@ -370,7 +442,8 @@ int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_
 // exact kernel and merge for n_users users (positions, if sel names a list) over nsplit item slices
 int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items, int32_t D,
                const int32_t *mask_ptr, const int32_t *mask_items, int32_t K, int32_t item_id_offset,
-               int nsplit, const UserSel &sel, float *out_scores, int32_t *out_ids, float *ps, hipStream_t st) {
+               int nsplit, const UserSel &sel, float *out_scores, int32_t *out_ids, float *ps, hipStream_t st,
+               const float *ceil_s = nullptr, const int32_t *ceil_id = nullptr) {
   const int kp = kpad_for(K);
   int32_t *pi = (int32_t *)(ps + (size_t)n_users * nsplit * kp);
   const int grid = (int)rk::ceil_div(n_users, UPB) * nsplit;
@@ -385,7 +458,7 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
     RK_EXACT_CASE(28)
     default:
       rc = launch_score_topk<32>(D / 64, grid, st, Uemb, n_users, Iemb, n_items, mask_ptr, mask_items, nsplit,
-                                 item_id_offset, sel.skip, sel.list, sel.count, sel.cap, ps, pi);
+                                 item_id_offset, sel.skip, sel.list, sel.count, sel.cap, ps, pi, ceil_s, ceil_id);
       break;
   }
 #undef RK_EXACT_CASE
@@ -449,6 +522,19 @@ struct TopkWorkspace {
 };
 inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
   TopkWorkspace w{};
+  if (K > kPage) {
+    // a paged ranking: the exact kernel's partial lists, one finished page (in the cand_* slots)
+    // and the rows' ceilings (unorm: scores, uexp: ids)
+    const int nsplit = choose_nsplit(n_users, n_items);
+    size_t off = 0;
+    w.part = off;    off += align256((size_t)n_users * nsplit * kPage * 8);
+    w.cand_s = off;  off += align256((size_t)n_users * kPage * 4);
+    w.cand_id = off; off += align256((size_t)n_users * kPage * 4);
+    w.unorm = off;   off += align256((size_t)n_users * 4);
+    w.uexp = off;    off += align256((size_t)n_users * 4);
+    w.total = off;
+    return w;
+  }
   const int kc = filter_len(K);
   // (the filter launch may use fewer slices than the exact one, never more)
   const int nsplit = choose_nsplit(n_users, n_items);
@@ -475,13 +561,37 @@ inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D,
   return w;
 }
 
+// K > kPage: pages of kPage places by the exact kernel, each bounded above by the page before
+int paged_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items, int32_t D,
+               const int32_t *mask_ptr, const int32_t *mask_items, int32_t K, int32_t item_id_offset,
+               float *out_scores, int32_t *out_ids, void *ws, hipStream_t st) {
+  const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
+  char *base = (char *)ws;
+  float *ps = (float *)(base + w.part), *page_s = (float *)(base + w.cand_s), *ceil_s = (float *)(base + w.unorm);
+  int32_t *page_id = (int32_t *)(base + w.cand_id), *ceil_id = (int32_t *)(base + w.uexp);
+  const int nsplit = choose_nsplit(n_users, n_items);
+  const int grid = (int)rk::ceil_div((int64_t)n_users * kPage, 256);
+  for (int32_t col0 = 0; col0 < K; col0 += kPage) {
+    const int rc = exact_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, kPage, 0, nsplit, UserSel{}, page_s,
+                              page_id, ps, st, col0 > 0 ? ceil_s : nullptr, col0 > 0 ? ceil_id : nullptr);
+    if (rc != RK_OK) return rc;
+    place_page_kernel<<<grid, 256, 0, st>>>(page_s, page_id, n_users, K, col0, item_id_offset, out_scores, out_ids, ceil_s,
+                                            ceil_id);
+    RK_CHECK_LAUNCH("place_page_kernel");
+  }
+  return RK_OK;
+}
+
 int check_topk_args(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items, int32_t D,
                     const int32_t *mask_ptr, const int32_t *mask_items, int32_t K, float *out_scores,
                     int32_t *out_ids, void *ws, size_t ws_bytes) {
   RK_CHECK_ARG(n_users > 0 && n_items > 0, "empty score matrix");
   // evalue/metric.py:9-10
   RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
-  if (K > 32) return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above the built maximum 32", K);
+  if (K > kMaxK) return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above the built maximum %d", K, kMaxK);
+  if (K > kPage && D != 64 && D != 128)
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above %d is built for embedding widths 64 and 128 (got %d)", K,
+                    kPage, D);
   RK_CHECK_ARG(D > 0 && D % 64 == 0, "embedding width must be a multiple of 64");
   RK_CHECK_ARG(Uemb && Iemb && out_scores && out_ids && ws, "null pointer");
   RK_CHECK_ARG((mask_ptr == nullptr) == (mask_items == nullptr), "mask_ptr and mask_items go together");
@@ -496,7 +606,7 @@ int check_topk_args(const float *Uemb, int32_t n_users, const float *Iemb, int32
 extern "C" {
 
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
-  if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > 32) return 0;
+  if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > kMaxK) return 0;
   return topk_workspace(n_users, n_items, D, K).total;
 }
 
@@ -515,6 +625,9 @@ int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users, const float *Iem
   const int rc = check_topk_args(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, out_scores,
                                  out_ids, ws, ws_bytes);
   if (rc != RK_OK) return rc;
+  if (K > kPage)
+    return paged_topk(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset, out_scores, out_ids, ws,
+                      (hipStream_t)stream);
   const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
   // widths the register-resident kernel is not built for: the kernel that walks the width in chunks
   if (D != 64 && D != 128)
@@ -605,8 +718,11 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
 }
 
 size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K) {
-  if (n_rows <= 0 || K <= 0 || K > 32) return 0;
-  return (size_t)n_rows * ROWS_LANES * kpad_for(K) * (sizeof(float) + sizeof(int32_t));
+  if (n_rows <= 0 || K <= 0 || K > kMaxK) return 0;
+  const size_t lists = (size_t)n_rows * ROWS_LANES * kpad_for(std::min(K, kPage)) * (sizeof(float) + sizeof(int32_t));
+  if (K <= kPage) return lists;
+  // paged: one finished page and the rows' ceilings behind the partial lists
+  return align256(lists) + 2 * align256((size_t)n_rows * kPage * 4) + 2 * align256((size_t)n_rows * 4);
 }
 
 int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items, int64_t ld, int32_t K,
@@ -614,15 +730,39 @@ int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items, int64
   RK_CHECK_ARG(n_rows >= 0 && n_items > 0 && ld >= n_items, "bad score matrix shape");
   // evalue/metric.py:9-10
   RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
-  if (K > 32) return rk::fail(RK_ERR_UNSUPPORTED, "rk_rows_topk_f32: K=%d above the built maximum 32", K);
+  if (K > kMaxK) return rk::fail(RK_ERR_UNSUPPORTED, "rk_rows_topk_f32: K=%d above the built maximum %d", K, kMaxK);
   if (n_rows == 0) return RK_OK;
   RK_CHECK_ARG(scores && out_scores && out_ids && ws, "null pointer");
   RK_CHECK_ARG(ws_bytes >= rk_rows_topk_ws_bytes(n_rows, K), "workspace too small");
   hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)rk::ceil_div(n_rows, 256 / ROWS_LANES);
+  if (K > kPage) {
+    // pages of kPage places, each bounded above by the last entry of the page before
+    char *base = (char *)ws;
+    float *ps = (float *)base;
+    int32_t *pi = (int32_t *)(ps + (size_t)n_rows * ROWS_LANES * kPage);
+    size_t off = align256((size_t)n_rows * ROWS_LANES * kPage * 8);
+    float *page_s = (float *)(base + off);    off += align256((size_t)n_rows * kPage * 4);
+    int32_t *page_id = (int32_t *)(base + off); off += align256((size_t)n_rows * kPage * 4);
+    float *ceil_s = (float *)(base + off);    off += align256((size_t)n_rows * 4);
+    int32_t *ceil_id = (int32_t *)(base + off);
+    const int pgrid = (int)rk::ceil_div((int64_t)n_rows * kPage, 256);
+    for (int32_t col0 = 0; col0 < K; col0 += kPage) {
+      if (col0 == 0)
+        rows_topk_kernel<kPage, false><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi);
+      else
+        rows_topk_kernel<kPage, true><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi, ceil_s, ceil_id);
+      RK_CHECK_LAUNCH("rows_topk_kernel");
+      const int rc = rk_topk_merge_f32(ps, pi, n_rows, ROWS_LANES, kPage, kPage, page_s, page_id, stream);
+      if (rc != RK_OK) return rc;
+      place_page_kernel<<<pgrid, 256, 0, st>>>(page_s, page_id, n_rows, K, col0, 0, out_scores, out_ids, ceil_s, ceil_id);
+      RK_CHECK_LAUNCH("place_page_kernel");
+    }
+    return RK_OK;
+  }
   const int kp = kpad_for(K);
   float *ps = (float *)ws;
   int32_t *pi = (int32_t *)(ps + (size_t)n_rows * ROWS_LANES * kp);
-  const int grid = (int)rk::ceil_div(n_rows, 256 / ROWS_LANES);
   switch (kp) {
     case 4: rows_topk_kernel<4><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
     case 8: rows_topk_kernel<8><<<grid, 256, 0, st>>>(scores, n_rows, n_items, ld, ps, pi); break;
@@ -657,15 +797,19 @@ int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_str
   for (int i = 0; i < MAXK; ++i) {
     kl.k[i] = i < nk ? k_list_host[i] : 0;
     if (i < nk) {
-      RK_CHECK_ARG(kl.k[i] >= 1 && kl.k[i] <= 32 && kl.k[i] <= id_stride,
-                   "k=%d outside [1, min(32, id_stride)]", kl.k[i]);
+      RK_CHECK_ARG(kl.k[i] >= 1 && kl.k[i] <= kMaxK && kl.k[i] <= id_stride,
+                   "k=%d outside [1, min(%d, id_stride)]", kl.k[i], kMaxK);
       if (kl.k[i] > kmax) kmax = kl.k[i];
     }
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)rk::ceil_div(n_users, 256);
-  rank_metrics_kernel<<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk,
-                                           kmax, discounts, (double *)ws);
+  if (kmax <= 32)
+    rank_metrics_kernel<1><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
+                                                (double *)ws);
+  else
+    rank_metrics_kernel<kMaxK / 32><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax,
+                                                        discounts, (double *)ws);
   RK_CHECK_LAUNCH("rank_metrics_kernel");
   rank_metrics_final_kernel<<<1, 1024, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
                                                out, sums_out);

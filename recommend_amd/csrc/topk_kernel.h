@@ -130,14 +130,19 @@ __device__ unsigned long long g_stamp[10];
 #define RK_ACC(i, a, b)
 #endif
 
-template <int KPAD, int DC, bool FILTER>
+// CEIL (exact scores only): a later page of a ranking longer than one list.  Only items that rank
+// strictly AFTER (ceil_s[u], ceil_id[u]) in the order (score descending, id ascending) -- the last
+// entry of the page before -- take part; ids are local to this table, like the lists'.
+template <int KPAD, int DC, bool FILTER, bool CEIL = false>
 __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_kernel(
     const float *__restrict__ Uemb, int32_t n_users,
     const float *__restrict__ Iemb, int32_t n_items,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items,
     int32_t nsplit, int32_t item_id_offset, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    float *__restrict__ part_s, int32_t *__restrict__ part_id, const int32_t *__restrict__ heavy_thresh) {
+    float *__restrict__ part_s, int32_t *__restrict__ part_id, const int32_t *__restrict__ heavy_thresh,
+    const float *__restrict__ ceil_s = nullptr, const int32_t *__restrict__ ceil_id = nullptr) {
+  static_assert(!(CEIL && FILTER), "pages are ranked by the exact kernel");
   constexpr int D = 64 * DC;
   // Exact scores: every wavefront streams its own copy of the item tiles through a private pair
   // of buffers (the MFMA chain is the bound, nothing is shared, no barriers).
@@ -247,6 +252,14 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
   // (behind every DMA in flight -- the counter is in order) for each masked item of the tile.
   int32_t next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
   int32_t next2_m = mcur + 1 < mend ? mask_items[mcur + 1] : INT32_MAX;
+  float page_s = INFINITY;
+  int32_t page_id = -1;
+  if constexpr (CEIL) {
+    if (user_ok) {
+      page_s = ceil_s[row_l];
+      page_id = ceil_id[row_l];
+    }
+  }
 
 #ifdef RK_STAMP
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -424,6 +437,15 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
         const uint32_t mh = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, 4 + (r & 3) + 8 * (r >> 2), 1);
         lo[r] = __uint_as_float((ml & __float_as_uint(kMasked)) | (~ml & __float_as_uint(lo[r])));
         hi[r] = __uint_as_float((mh & __float_as_uint(kMasked)) | (~mh & __float_as_uint(hi[r])));
+      }
+    }
+    if constexpr (CEIL) {
+      // (after the mask: a masked item ranks with the mask score, on this page or an earlier one)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int32_t il = item0 + (r & 3) + 8 * (r >> 2), ih = il + 4;
+        if (lo[r] > page_s || (lo[r] == page_s && il <= page_id)) lo[r] = -INFINITY;
+        if (hi[r] > page_s || (hi[r] == page_s && ih <= page_id)) hi[r] = -INFINITY;
       }
     }
   };
