@@ -192,7 +192,10 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)   # BENCH_BACKEND=gloo rehearsals share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: run the N > 1 code (process group, sharded evaluators, row-sharded legs) with
+    # whatever world size the launcher gave, one rank included -- a rehearsal of the collectives on one GPU
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if dist_on:
         backend = os.environ.get("BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -233,7 +236,7 @@ def main():
         raise RuntimeError("the model forward produced non-finite embeddings: nothing measured on them would mean anything")
 
     # ---------------------------------------------------------------- evaluation (the timed step)
-    if world > 1:
+    if dist_on:
         # users are independent units: every rank ranks its block of users against the whole item table,
         # no candidate lists cross ranks (the item-sharded form is timed further down, beside it)
         ev = UserShardedRankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, U, I, rank, world)
@@ -241,17 +244,17 @@ def main():
         ev = RankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, n_users=U)
     for _ in range(args.warmup):
         res = ev.evaluate(ue, ie)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = ev.evaluate(ue, ie)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         from recommend_amd.dist import all_reduce_tensor
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce_tensor(t, dist.ReduceOp.MAX)
@@ -262,14 +265,14 @@ def main():
     # dominant kernels of the step: the fused score + mask + top-K launch sequence.  At this size
     # it is the fp16 candidate filter + exact re-scoring (results identical to the exact fp32
     # kernel, which is timed beside it against its own, fp32-input MFMA peak).
-    u_loc = U if world == 1 else (ev.u_hi - ev.u_lo)     # this rank's share of the score matrix
-    topk_fn = (lambda: ev.topk(ue, ie, 20)) if world == 1 else (lambda: ev.local_topk(ue, ie, 20))
+    u_loc = U if not dist_on else (ev.u_hi - ev.u_lo)     # this rank's share of the score matrix
+    topk_fn = (lambda: ev.topk(ue, ie, 20)) if not dist_on else (lambda: ev.local_topk(ue, ie, 20))
     topk_fn()
     ms_topk = event_ms(topk_fn, max(3, args.steps))
     topk_calls = args.warmup + args.steps + 1 + max(3, args.steps)
     flop = 2.0 * u_loc * I * D
     tflops = flop / (ms_topk * 1e-3) / 1e12
-    filtered = u_loc * I >= (1 << 29) and D in (64, 128)   # what rk_score_topk_f32 decides
+    filtered = u_loc * I >= (1 << 27) and D in (64, 128)   # what rk_score_topk_f32 decides
     peak = MFMA_F16_PEAK_TFS if filtered else MFMA_F32_PEAK_TFS
     traffic_topk, traffic_topk_src = pmc_traffic("score_topk_call", args.shape, D, world)
     roofline = {"kernel": ("score_topk_kernel<fp16 filter> + merge + refine + exact fallback (one rk_score_topk_f32 call)"
@@ -283,7 +286,7 @@ def main():
                 "note": ("peak is the dense fp16 MFMA rate, the arithmetic of the dominant kernel; that kernel is bound "
                          "by the vector instructions of the top-K selection, not by the matrix pipe" if filtered else "")}
     roofline_exact = None
-    if world == 1 and not args.pmc_pass:
+    if not dist_on and not args.pmc_pass:
         exact_fn = lambda: ev.topk(ue, ie, 20, mode="exact")
         exact_fn()
         ms_exact = event_ms(exact_fn, max(3, args.steps))
@@ -312,7 +315,7 @@ def main():
 
     # ---------------------------------------------------------------- one training epoch
     epoch = None
-    if args.epoch_steps != 0 and world == 1:
+    if args.epoch_steps != 0 and not dist_on:
         p_ptr, p_items = build_user_csr(data.users, data.items, U)
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
         dp, di = sampler.device_csr(dev)
@@ -351,7 +354,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_users > 0:
+    if rank == 0 and not dist_on and args.cpu_users > 0:
         v, dt, cores, n = cpu_baseline_eval(ue.cpu().numpy(), ie.cpu().numpy(), (tu, ti), (vu, vi), args.cpu_users)
         cpu = {"value": round(v, 1), "unit": "users/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
                "sample": f"reference-style verify (matmul, index_put -1e10, topk x3, metrics) on the first {n} "
@@ -395,7 +398,7 @@ def main():
             }
             if args.pmc_pass:
                 line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
-            if world > 1:
+            if dist_on:
                 line["item_sharded_eval"] = user_sharded
                 line["row_sharded_hop"] = sharded_hop
                 line["row_sharded_train_step"] = sharded_train
@@ -405,7 +408,7 @@ def main():
     # one of them never return (they have run over gloo only), every rank gives up after a while and rank 0
     # prints the line with what has been measured.
     watchdog = None
-    if world > 1:
+    if dist_on:
         import threading
 
         def give_up():
@@ -419,7 +422,7 @@ def main():
         watchdog = threading.Timer(float(os.environ.get("BENCH_LEG_LIMIT_S", "420")), give_up)
         watchdog.daemon = True
         watchdog.start()
-    if world > 1:
+    if dist_on:
         try:
             from recommend_amd.dist import all_reduce_tensor
             ev_u = ShardedRankingEvaluator((vu, vi), (tu, ti), K_LIST, METRICS, U, I, rank, world)
@@ -444,7 +447,7 @@ def main():
     # N > 1: the row-sharded forms, outside the timed region; the slowest rank counts.
     # (a) one propagation hop (all-gather of the layer over RCCL + local SpMM on the rank's rows),
     # (b) the whole MMFCN training step with rows and batch sharded (recommend_amd.dist_train).
-    if world > 1:
+    if dist_on:
         from recommend_amd.dist import RowShardedGraph, all_reduce_tensor
         try:
             wn = gc.graph.edata[gc.weight].detach().cpu().numpy()
@@ -500,7 +503,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     emit()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -515,10 +515,37 @@ inline int filter_nsplit(int n_users, int n_items, int kc, int D) {
 // (8 places of margin between the K-th exact and the last filter score, 4 at least)
 inline int filter_len(int K) { return K + 8 <= 32 ? std::max(8, kpad_for(K + 8)) : (K + 4 <= 32 ? 32 : 0); }
 
+// Item slices of the threshold filter's two passes: whatever fills the chip.  A slice costs no list
+// start-up there (topk_threshold.h), only its 64 strata maxima and candidate places per user; slices
+// are whole groups of four tiles.
+inline int threshold_nsplit(int n_users, int n_items, int D) {
+  const int64_t groups = rk::ceil_div(rk::ceil_div(n_items, TI), 4);
+  const int ns = choose_nsplit(n_users, n_items, D == 64 ? 3 : 2);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(ns, groups));
+}
+
+// Which form of the filter a shape takes.  The list form (score_topk_kernel on fp16 rows) pays the
+// start-up of a sorted list per user and item slice; on a long table walked in ONE slice that is
+// amortised and one pass over the scores beats two (Elec, 192k x 63k: 3.0 ms against 1.7 + 2.3).
+// Whenever the list form would cut the table into three or more slices to fill the chip (few users:
+// a small data set, a rank's block of a user-sharded evaluation) or the table is short (an item
+// shard), the threshold form (topk_threshold.h) is faster: 19k x 7k 0.66 -> 0.37 ms, 36k x 18k
+// 0.90 -> 0.60, 39k x 23k 0.91 -> 0.72, 48k x 63k 1.58 -> 1.27, 24k x 63k 1.16 -> 0.79 (whole calls; at
+// two slices, 96k x 63k, the lists still lead 2.23 to 2.31).  Both give the exact kernel's result.
+// RK_FILTER_FORM=lists|threshold in the environment (read at every call) overrides the choice:
+// a knob for the parity tests, which run every case through both forms.
+inline bool threshold_form(int n_users, int n_items, int kc, int D) {
+  if (const char *f = getenv("RK_FILTER_FORM")) {
+    if (f[0] == 'l') return false;
+    if (f[0] == 't') return true;
+  }
+  return filter_nsplit(n_users, n_items, kc, D) > 2 || rk::ceil_div(n_items, TI) <= kShortTableTiles;
+}
+
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct TopkWorkspace {
-  size_t part, uhalf, ihalf, unorm, umax, uexp, istats, open_count, heavy, stats_part, open_list, cand_s, cand_id, done, total;
+  size_t part, uhalf, ihalf, unorm, umax, uexp, istats, open_count, heavy, stats_part, open_list, cand_s, cand_id, done, thr, cnt, cand, total;
 };
 inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
   TopkWorkspace w{};
@@ -543,6 +570,9 @@ inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D,
   w.part = off;
   size_t part_entries = std::max((size_t)n_users * std::max(nsplit, 2) * klen, open_part_entries(n_users, n_items, K));
   if (D != 64 && D != 128) part_entries = std::max(part_entries, rk::wide_part_entries(n_users, n_items, K));
+  // (the strata maxima of the threshold filter live here too: dead before the exact kernel's lists are written)
+  const int tsplit = threshold_nsplit(n_users, n_items, D);
+  part_entries = std::max(part_entries, rk::threshold_strata_bytes(n_users, tsplit) / 8 + 1);
   off += align256(part_entries * 8);
   w.uhalf = off;   off += align256((size_t)n_users * D * 2);
   w.ihalf = off;   off += align256((size_t)n_items * D * 2);
@@ -557,6 +587,9 @@ inline TopkWorkspace topk_workspace(int32_t n_users, int32_t n_items, int32_t D,
   w.cand_s = off;  off += align256((size_t)n_users * std::max(kc, 1) * 4);
   w.cand_id = off; off += align256((size_t)n_users * std::max(kc, 1) * 4);
   w.done = off;    off += align256((size_t)n_users * 4);
+  w.thr = off;     off += align256((size_t)n_users * 4);
+  w.cnt = off;     off += align256((size_t)n_users * tsplit * 4);
+  w.cand = off;    off += align256(rk::threshold_cand_bytes(n_users, tsplit));
   w.total = off;
   return w;
 }
@@ -642,10 +675,10 @@ int rk_score_topk_f32(const float *Uemb, int32_t n_users, const float *Iemb, int
                       int32_t D, const int32_t *mask_ptr, const int32_t *mask_items, int32_t K,
                       int32_t item_id_offset, float *out_scores, int32_t *out_ids, void *ws,
                       size_t ws_bytes, void *stream) {
-  // The filter's dozen launches cost about a millisecond whatever the size; measured crossover:
-  // 19k x 7k (1.4e8 scores) exact 0.46 ms / filter 0.96 ms, 36k x 18k (6.5e8) 1.41 / 0.97,
-  // 39k x 23k (9.1e8) 1.61 / 1.05.  From 2^29 scores up the filter wins.
-  if ((int64_t)n_users * n_items < ((int64_t)1 << 29))
+  // The filter's dozen launches cost a few tenths of a millisecond whatever the size; measured:
+  // 19k x 7k (1.4e8 scores) exact 0.46 ms / filter 0.37 ms, 36k x 18k (6.5e8) 1.45 / 0.61,
+  // 39k x 23k (9.1e8) 1.64 / 0.74.  From 2^27 scores up the filter wins.
+  if ((int64_t)n_users * n_items < ((int64_t)1 << 27))
     return rk_score_topk_exact_f32(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
                                    out_scores, out_ids, ws, ws_bytes, stream);
   return rk_score_topk_filtered_f32(Uemb, n_users, Iemb, n_items, D, mask_ptr, mask_items, K, item_id_offset,
@@ -684,8 +717,23 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   if ((rc = rk::half_rows(Uemb, n_users, D, true, uhalf, unorm, umax, uexp, nullptr, nullptr, st)) != RK_OK) return rc;
   if ((rc = rk::half_rows(Iemb, n_items, D, false, ihalf, nullptr, nullptr, nullptr, stats_part, istats, st)) != RK_OK)
     return rc;
-  // 2. the kc best filter scores per user (local item ids)
   float *ps = (float *)(base + w.part);
+  if (threshold_form(n_users, n_items, kc, D)) {
+    // 2. strata maxima -> per-user threshold -> every item at or above it as a candidate
+    const int tsplit = threshold_nsplit(n_users, n_items, D);
+    float *thr = (float *)(base + w.thr);
+    int32_t *cnt = (int32_t *)(base + w.cnt);
+    void *cand = base + w.cand;
+    if ((rc = rk::threshold_candidates(kc, D, tsplit, st, uhalf, n_users, ihalf, n_items, mask_ptr, mask_items, heavy_thresh,
+                                       ps, thr, cand, cnt)) != RK_OK)
+      return rc;
+    // 3. exact scores of the candidates, final order, certification
+    if ((rc = rk::refine_threshold_candidates(Uemb, Iemb, n_users, n_items, D, cand, cnt, tsplit, thr, K, mask_ptr, heavy_thresh,
+                                              unorm, uexp, istats, item_id_offset, out_scores, out_ids, done, open_count,
+                                              open_list, kOpenCap, st)) != RK_OK)
+      return rc;
+  } else {
+  // 2. the kc best filter scores per user (local item ids)
   int32_t *pi = (int32_t *)(ps + (size_t)n_users * fsplit * kc);
   const int grid = (int)rk::ceil_div(n_users, UPB) * fsplit;
   // a single slice's lists ARE the candidates (sorted, unfilled places -inf / -1): no merge
@@ -705,6 +753,7 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
                                   uexp, istats, item_id_offset, out_scores, out_ids, done, open_count, open_list,
                                   kOpenCap, st)) != RK_OK)
     return rc;
+  }
   // 4. the exact kernel for the users that could not be certified: the listed ones as a compact
   //    launch; if the list overflowed (then that launch does nothing), everybody whose flag is 0
   UserSel listed, flagged;

@@ -14,8 +14,11 @@
 // therefore the exact kernel's result in every case.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "topk_filter.h"
 #include "topk_kernel.h"
+#include "topk_threshold.h"
 
 namespace {
 
@@ -288,6 +291,87 @@ __global__ __launch_bounds__(256) void refine_kernel(
   }
 }
 
+// The threshold filter's counterpart of refine_kernel: one wavefront per user, one lane per
+// candidate.  The candidates are ALL items whose filter score is >= thr[user] (cnt per item slice,
+// at most kCandCap taking part), in no particular order: every one is scored exactly, the best K by
+// (score desc, id asc) are written, and done[user] = 1 iff no other item can rank among them: every
+// item outside has a filter score below thr, hence an exact score below thr + eps.
+__global__ __launch_bounds__(256) void refine_wide_kernel(
+    const float *__restrict__ Uemb, const float *__restrict__ Iemb, int32_t n_users, int32_t n_items, int D,
+    const uintx2 *__restrict__ cand, const int32_t *__restrict__ cnt, int nsplit, const float *__restrict__ thr, int K,
+    const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ heavy_thresh, const float *__restrict__ unorm,
+    const int32_t *__restrict__ uexp, const float *__restrict__ istats, int32_t item_id_offset,
+    float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
+    int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
+  const int wave = threadIdx.x / rk::kWave, lane = threadIdx.x % rk::kWave;
+  const int32_t user = blockIdx.x * 4 + wave;
+  if (user >= n_users) return;   // wave-uniform
+  int32_t total = 0;
+  bool over = false;
+  int64_t my_place = -1;
+  for (int sl = 0; sl < nsplit; ++sl) {
+    int32_t c = cnt[(int64_t)user * nsplit + sl];
+    if (c > kCandCap) {
+      over = true;
+      c = kCandCap;
+    }
+    if (lane >= total && lane < total + c) my_place = ((int64_t)user * nsplit + sl) * kCandCap + (lane - total);
+    total += c;
+  }
+  if (total > rk::kWave) over = true;
+  const bool valid = my_place >= 0;
+  int32_t id = -1;
+  float approx = -INFINITY;
+  if (valid) {
+    const uintx2 e = cand[my_place];
+    approx = __uint_as_float(e.x);
+    id = (int32_t)e.y;
+  }
+  const bool masked = approx == kMasked;   // (a product of fp16 rows is at most D in magnitude)
+  float s = -INFINITY;
+  if (valid) s = masked ? kMasked : exact_score(Uemb + (int64_t)user * D, Iemb + (int64_t)id * D, D);
+  // rank among the candidates by (score desc, id asc); ids are distinct
+  const int n = __builtin_amdgcn_readfirstlane(min(total, (int32_t)rk::kWave));
+  int rank = 0;
+  for (int l = 0; l < n; ++l) {
+    const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), l));
+    const int32_t il = __builtin_amdgcn_readlane(id, l);
+    rank += (sl > s || (sl == s && il < id)) ? 1 : 0;
+  }
+  if (valid && rank < K) {
+    out_s[(int64_t)user * K + rank] = s;
+    out_id[(int64_t)user * K + rank] = id + item_id_offset;
+  }
+  // certification, in the units of the exact scores: the filter worked on u * 2^-eu and i * 2^-ei
+  const int e_sum = uexp[user] + scale_exponent(istats[1]);
+  const float back = ldexpf(1.0f, e_sum);           // inf / 0 at absurd magnitudes: nothing certified
+  const int n_valid = __popcll(__ballot(valid));
+  // (an exact score that is NaN or -inf has no place in the order above: the exact kernel, in
+  // which neither ever ranks, settles such a user)
+  const bool has_nan = __ballot(valid && !(s > -INFINITY)) != 0;
+  const uint64_t kth = __ballot(valid && rank == K - 1);
+  const float tau_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), kth ? __ffsll((long long)kth) - 1 : 0));
+  const float tau = kth ? tau_l : INFINITY;
+  if (lane == 0) {
+    // |filter - exact| <= eps, as in refine_kernel
+    const float eps = 1.25f * 0x1p-10f * unorm[user] * istats[0] + (float)D * 0x1p-22f * back + 1e-30f;
+    const float t = thr[user];
+    // every item outside the candidates has a filter score below t (masked ones the mask score)
+    const float bound = t == kMasked ? kMasked : t * back;
+    // The K-th score must also lie above the mask score: the filter ranks masked items below every
+    // real score of its (rescaled) units, the exact kernel ranks them at -1e10, above real scores
+    // that are lower still.  (users with very long training lists were not masked: kHeavyUsers)
+    const bool heavy = heavy_thresh != nullptr && mask_ptr[user + 1] - mask_ptr[user] > heavy_thresh[0];
+    const bool ok = !heavy && !over && !has_nan && n_valid >= K &&
+                    (total >= n_items || (bound + eps < tau && tau > kMasked));
+    done[user] = ok ? 1 : 0;
+    if (!ok) {   // left to the exact kernel: listed (in any order) while the list has room
+      const int32_t pos = atomicAdd(open_count, 1);
+      if (pos < open_cap) open_list[pos] = user;
+    }
+  }
+}
+
 // hist[b]: users whose training list has bit length b (length in [2^(b-1), 2^b))
 __global__ __launch_bounds__(256) void mask_hist_kernel(const int32_t *__restrict__ mask_ptr, int32_t n_users,
                                                         int32_t *__restrict__ hist) {
@@ -399,5 +483,55 @@ int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int
   RK_CHECK_LAUNCH("refine_kernel");
   return RK_OK;
 }
+
+int threshold_candidates(int kc, int D, int32_t nsplit, hipStream_t st, const float *Uhalf, int32_t n_users,
+                         const float *Ihalf, int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items,
+                         const int32_t *heavy_thresh, float *strata, float *thr, void *cand, int32_t *cnt) {
+  const int grid = (int)ceil_div(n_users, UPB) * nsplit;
+  const int tgrid = (int)ceil_div(n_users, 256);
+  const int32_t per_user = nsplit * kStrata;
+  if (D != 64 && D != 128) return fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", D);
+  RK_CHECK_ARG(threshold_cand_bytes(n_users, nsplit) < ((size_t)1 << 32), "top-K filter: candidate places beyond 4 GiB");
+  if (D == 64)
+    strata_max_kernel<1, 3><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
+  else
+    strata_max_kernel<2, 2><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
+  RK_CHECK_LAUNCH("strata_max_kernel");
+  switch (kc) {
+    case 8: strata_threshold_kernel<8><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 12: strata_threshold_kernel<12><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 16: strata_threshold_kernel<16><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 20: strata_threshold_kernel<20><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 24: strata_threshold_kernel<24><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 28: strata_threshold_kernel<28><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 32: strata_threshold_kernel<32><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    default: return fail(RK_ERR_UNSUPPORTED, "top-K filter: candidate list length %d not built", kc);
+  }
+  RK_CHECK_LAUNCH("strata_threshold_kernel");
+  if (D == 64)
+    collect_kernel<1, 3><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, thr,
+                                               (uintx2 *)cand, cnt);
+  else
+    collect_kernel<2, 2><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, thr,
+                                               (uintx2 *)cand, cnt);
+  RK_CHECK_LAUNCH("collect_kernel");
+  return RK_OK;
+}
+
+int refine_threshold_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
+                                const void *cand, const int32_t *cnt, int32_t nsplit, const float *thr, int K,
+                                const int32_t *mask_ptr, const int32_t *heavy_thresh, const float *unorm,
+                                const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
+                                int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
+                                int32_t open_cap, hipStream_t st) {
+  refine_wide_kernel<<<(unsigned)ceil_div(n_users, 4), 256, 0, st>>>(
+      Uemb, Iemb, n_users, n_items, D, (const uintx2 *)cand, cnt, nsplit, thr, K, mask_ptr, heavy_thresh, unorm, uexp,
+      istats, item_id_offset, out_s, out_id, done, open_count, open_list, open_cap);
+  RK_CHECK_LAUNCH("refine_wide_kernel");
+  return RK_OK;
+}
+
+size_t threshold_strata_bytes(int32_t n_users, int32_t nsplit) { return (size_t)n_users * nsplit * kStrata * sizeof(float); }
+size_t threshold_cand_bytes(int32_t n_users, int32_t nsplit) { return (size_t)n_users * nsplit * kCandCap * 8; }
 
 }  // namespace rk

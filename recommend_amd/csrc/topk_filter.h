@@ -40,4 +40,25 @@ int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int
                       int32_t *done, int32_t *open_count, int32_t *open_list, int32_t open_cap,
                       hipStream_t st);
 
+// The threshold form of the filter (topk_threshold.h): per user and item slice the running maxima
+// of kStrata strata (strata: threshold_strata_bytes of scratch), thr[user] = the kc-th largest of a
+// user's maxima, then every item whose filter score is >= thr[user] as a candidate: cand
+// (threshold_cand_bytes) holds (score bits, local item id) pairs, cnt[user * nsplit + slice] their
+// number.  Slices are whole groups of four tiles.
+int threshold_candidates(int kc, int D, int32_t nsplit, hipStream_t st, const float *Uhalf, int32_t n_users,
+                         const float *Ihalf, int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items,
+                         const int32_t *heavy_thresh, float *strata, float *thr, void *cand, int32_t *cnt);
+size_t threshold_strata_bytes(int32_t n_users, int32_t nsplit);
+size_t threshold_cand_bytes(int32_t n_users, int32_t nsplit);
+
+// refine_candidates for the threshold form: all candidates of a user (at most 64 take part) are
+// scored exactly; done[user] = 1 iff thr[user] plus the filter's error bound is below the K-th
+// exact score (or every item is a candidate).
+int refine_threshold_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int32_t n_items, int D,
+                                const void *cand, const int32_t *cnt, int32_t nsplit, const float *thr, int K,
+                                const int32_t *mask_ptr, const int32_t *heavy_thresh, const float *unorm,
+                                const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
+                                int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
+                                int32_t open_cap, hipStream_t st);
+
 }  // namespace rk

@@ -44,6 +44,15 @@ def dev(a, dtype=None):
     return t.to(DEV) if dtype is None else t.to(DEV, dtype)
 
 
+@pytest.fixture(autouse=True, params=["lists", "threshold"])
+def filter_form(request, monkeypatch):
+    """The candidate filter has two forms (sorted lists per user in one pass; strata maxima ->
+    threshold -> candidates in two) and picks one by shape; every case here runs through both
+    (RK_FILTER_FORM is read by the library at every call)."""
+    monkeypatch.setenv("RK_FILTER_FORM", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["v96x300", "v200x1000"])
 def test_verifier_and_tester_vs_reference(golden, name):
     z = golden("verifier_cases.npz")

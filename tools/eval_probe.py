@@ -42,9 +42,6 @@ for name in ("rk_score_topk_exact_f32", "rk_score_topk_filtered_f32"):
     ms = s.elapsed_time(e) / a.reps
     out[name] = (os_, oi)
     print(f"{name} {a.shape} K={a.k} D={a.dim}: {ms:.3f} ms  {2.0*d.n_users*d.n_items*a.dim/ms/1e9:.1f} TFLOP/s equiv")
-done_off = (ws_bytes - ((4 * d.n_users + 255) // 256) * 256) // 4
-done = ws[done_off:done_off + d.n_users].view(torch.int32)
-print("users left to the exact pass:", int((done == 0).sum()), "of", d.n_users)
 (es, ei), (fs, fi) = out["rk_score_topk_exact_f32"], out["rk_score_topk_filtered_f32"]
 print("ids equal:", bool(torch.equal(ei, fi)), " scores bit-equal:", bool(torch.equal(es.view(torch.int32), fs.view(torch.int32))))
 if not torch.equal(ei, fi):
