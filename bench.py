@@ -460,6 +460,17 @@ def main():
             sharded_hop = {"ms_per_hop": round(float(t), 5), "rows_per_rank": rg.block,
                            "all_gather_bytes_total": N * D * 4,
                            "note": "all-gather of the layer + SpMM on this rank's rows; max over ranks"}
+            # the same hop with the halo exchange: one all-to-all of exactly the rows each rank's edges read
+            rg.enable_halo()
+            rg.hop(h_loc)
+            dist.barrier()
+            t = torch.tensor([event_ms(lambda: rg.hop(h_loc), 20)], dtype=torch.float64, device=dev)
+            all_reduce_tensor(t, dist.ReduceOp.MAX)
+            halo = torch.tensor([float(rg.halo_rows()[0]) if rg.halo_rows() else 0.0], dtype=torch.float64, device=dev)
+            all_reduce_tensor(halo, dist.ReduceOp.SUM)
+            sharded_hop["halo"] = {"ms_per_hop": round(float(t), 5), "rows_received_total": int(halo),
+                                   "bytes_total": int(halo) * D * 4,
+                                   "note": "all-to-all of the rows each rank's edges read (dist.HaloPlan) + the same SpMM"}
             del rg
         except Exception as e:  # reported, never fatal for the headline line
             sharded_hop = {"error": repr(e)}

@@ -11,7 +11,9 @@ sums of its slice and one all-reduce of 6*len(k_list) doubles finishes the means
 Contiguous item ranges keep "lower id wins" valid across shards.
 
 Propagation over graphs too large for one GPU shards the ROWS (RowShardedGraph at the
-end of this file): one all-gather of the layer per hop, forward and backward.
+end of this file): one exchange of layer rows per hop, forward and backward -- an all-gather
+of the whole layer, or (exchange="halo") one all-to-all that brings every rank exactly the
+rows its own edges reference.
 
 The reference is single-process (no collective anywhere in its tree); this file
 has no counterpart there.  `compute` is the module that provides score_topk /
@@ -272,6 +274,90 @@ class HipRowBlock:
         """beta * (A_rows h_full) [+ alpha * h0], the epilogue fused into the SpMM kernel."""
         return self._ops.spmm_raw(self.mat, h_full, h0, alpha, beta)
 
+    def remap_columns(self, col, n_cols):
+        """The same rows and values with other column ids (same order): the operand then gathers
+        from a matrix of n_cols rows (HaloPlan)."""
+        self.mat.idx = torch.from_numpy(np.ascontiguousarray(col if len(col) else np.zeros(1, np.int32), np.int32)).to(self.mat.device)
+        self.mat.n_cols = int(n_cols)
+
+
+def _collective_device(group, device):
+    """Where the tensors of a collective live: on the GPU for nccl, on the host for gloo."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device(device)
+
+
+class HaloPlan:
+    """Which rows of the other ranks' blocks the columns of one row block reference, and the
+    exchange that fetches exactly those: rank r sends rank q the rows of its block that q's edges
+    read, in one all_to_all_single per hop (sum over ranks of their halo rows x D x 4 bytes
+    instead of the N x D x 4 of an all-gather).  The block's column ids are renumbered to the
+    compact matrix [own rows | rows from rank 0 | rows from rank 1 | ...] the exchange fills, so no
+    rank holds a buffer of N rows.
+
+    What it buys depends on the graph: a rank's halo is the set of distinct columns outside its own
+    block, at most min(N - n_local, edges of the block).  A graph whose row blocks reference most
+    of the other nodes (the synthetic scale-up shape: 61 M edges per block into 12 M nodes) moves
+    nearly as much as the all-gather; graphs with locality, or many ranks with few edges each, move
+    a fraction."""
+
+    def __init__(self, cols, lo, hi, block, rank, world, group=None, device="cpu"):
+        cols = np.asarray(cols, np.int64)
+        self.lo, self.hi, self.block, self.rank, self.world, self.group = lo, hi, block, rank, world, group
+        self.n_local = hi - lo
+        outside = cols[(cols < lo) | (cols >= hi)]
+        self.need = np.unique(outside)                      # ascending global ids = grouped by owner rank
+        owner = self.need // block
+        recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        cdev = _collective_device(group, device)
+        # every owner learns how many, then which, of its rows this rank reads
+        rc = torch.from_numpy(recv_counts).to(cdev)
+        sc = torch.empty_like(rc)
+        dist.all_to_all_single(sc, rc, group=group)
+        send_counts = sc.cpu().numpy()
+        want = torch.from_numpy(self.need - owner * block).to(cdev)      # row numbers inside the owner's block
+        give = torch.empty(int(send_counts.sum()), dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(give, want, [int(c) for c in send_counts], [int(c) for c in recv_counts], group=group)
+        self.send_idx = give.to(device)                     # rows of x_local to pack, by destination rank
+        self.send_splits = [int(c) for c in send_counts]
+        self.recv_splits = [int(c) for c in recv_counts]
+        self.n_halo = int(self.need.shape[0])
+        self.n_send = int(send_counts.sum())
+        self.device = torch.device(device)
+        self._bufs = {}
+
+    def remap(self, cols):
+        """Global column ids -> rows of the compact matrix."""
+        cols = np.asarray(cols, np.int64)
+        own = (cols >= self.lo) & (cols < self.hi)
+        out = np.empty(cols.shape[0], np.int64)
+        out[own] = cols[own] - self.lo
+        out[~own] = self.n_local + np.searchsorted(self.need, cols[~own])
+        return out.astype(np.int32)
+
+    def exchange(self, x_local):
+        """[n_local, D] on every rank -> [n_local + n_halo, D]: the rank's own rows followed by the
+        rows it reads from the others.  The result lives in a buffer that the next exchange of the
+        same width overwrites."""
+        x = x_local.detach()
+        D = x.shape[1]
+        key = (D, x.dtype)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            bufs = (torch.empty((self.n_local + self.n_halo, D), dtype=x.dtype, device=x.device),
+                    torch.empty((self.n_send, D), dtype=x.dtype, device=x.device))
+            self._bufs[key] = bufs
+        buf, send = bufs
+        buf[: self.n_local].copy_(x)
+        if self.n_send:
+            torch.index_select(x, 0, self.send_idx, out=send)
+        if _via_host(self.group) and x.is_cuda:
+            got = torch.empty((self.n_halo, D), dtype=x.dtype)
+            dist.all_to_all_single(got, send.cpu(), self.recv_splits, self.send_splits, group=self.group)
+            buf[self.n_local:].copy_(got)
+        else:
+            dist.all_to_all_single(buf[self.n_local:], send, self.recv_splits, self.send_splits, group=self.group)
+        return buf
+
 
 class _ShardedHop(torch.autograd.Function):
     """out_local = alpha * h0_local + beta * (A_rows gather(h_local)).  Backward:
@@ -281,7 +367,7 @@ class _ShardedHop(torch.autograd.Function):
     def forward(ctx, h_local, h0_local, graph, alpha, beta):
         ctx.graph, ctx.alpha, ctx.beta = graph, alpha, beta
         ctx.has_h0 = h0_local is not None
-        return graph.fwd.matmul(graph.gather_rows(h_local), h0_local, alpha, beta)
+        return graph.fwd.matmul(graph.inputs(h_local, "fwd"), h0_local, alpha, beta)
 
     @staticmethod
     def backward(ctx, g_local):
@@ -289,7 +375,7 @@ class _ShardedHop(torch.autograd.Function):
         g_local = g_local.contiguous()
         gh = gh0 = None
         if ctx.needs_input_grad[0]:
-            gh = graph.bwd.matmul(graph.gather_rows(g_local), None, 0.0, ctx.beta)
+            gh = graph.bwd.matmul(graph.inputs(g_local, "bwd"), None, 0.0, ctx.beta)
         if ctx.has_h0 and ctx.needs_input_grad[1]:
             gh0 = g_local * ctx.alpha
         return gh, gh0, None, None, None
@@ -302,17 +388,26 @@ class RowShardedGraph:
     its normalised values) and keeps its rows only.  RowShardedGraph.from_local_edges(...): the rank
     hands over only the edges it owns (no rank holds the whole list).
     `block_factory(rowptr, col, val, device, n_cols=...)` returns an object with
-    `matmul(h_full, h0, alpha, beta)`; HipRowBlock in production."""
+    `matmul(h_full, h0, alpha, beta)` and `remap_columns(col, n_cols)`; HipRowBlock in production.
+    exchange: "allgather" (every hop gathers the whole layer into an N-row buffer) or "halo" (every
+    hop brings exactly the rows this rank's edges read: HaloPlan; `enable_halo()` switches a graph
+    over after anything that needs global column ids -- the normalisation -- has run)."""
 
     def __init__(self, src, dst, w, n_nodes, rank=None, world=None, group=None, device="cuda",
-                 block_factory=None):
+                 block_factory=None, exchange="allgather"):
         self._init_partition(n_nodes, rank, world, group, device)
         factory = block_factory or HipRowBlock
         w = np.asarray(w, np.float32)
         p, c, e = _rows_csr(dst, src, self.lo, self.hi)       # out[v] = sum over edges u -> v
         self.fwd = factory(p, c, w[e], device, n_cols=self.n_nodes)
+        self._cols["fwd"] = c
         p, c, e = _rows_csr(src, dst, self.lo, self.hi)       # rows of the transposed operand
         self.bwd = factory(p, c, w[e], device, n_cols=self.n_nodes)
+        self._cols["bwd"] = c
+        if exchange == "halo":
+            self.enable_halo()
+        elif exchange != "allgather":
+            raise ValueError(f"unknown exchange {exchange!r} (allgather, halo)")
 
     def _init_partition(self, n_nodes, rank, world, group, device):
         self.group = group
@@ -323,6 +418,9 @@ class RowShardedGraph:
         self.lo, self.hi = node_range(self.n_nodes, self.rank, self.world)
         self.device = torch.device(device)
         self._gather_buf = {}
+        self._cols = {}          # global column ids of the two blocks (host), until a halo plan renumbers them
+        self._plans = {}
+        self.exchange = "allgather"
 
     @classmethod
     def from_local_edges(cls, fwd_rows, bwd_rows, n_nodes, rank=None, world=None, group=None, device="cuda",
@@ -335,7 +433,33 @@ class RowShardedGraph:
         factory = block_factory or HipRowBlock
         g.fwd = factory(*fwd_rows, device, n_cols=g.n_nodes)
         g.bwd = factory(*bwd_rows, device, n_cols=g.n_nodes)
+        g._cols = {"fwd": np.asarray(fwd_rows[1]), "bwd": np.asarray(bwd_rows[1])}
         return g
+
+    def enable_halo(self):
+        """Switch the hops to the halo exchange: the blocks' columns are renumbered to the compact
+        [own rows | halo rows] matrices the exchanges fill (a collective: every rank calls it)."""
+        if self.world == 1 or self.exchange == "halo":
+            return self
+        for name, block in (("fwd", self.fwd), ("bwd", self.bwd)):
+            plan = HaloPlan(self._cols[name], self.lo, self.hi, self.block, self.rank, self.world, self.group, self.device)
+            block.remap_columns(plan.remap(self._cols[name]), plan.n_local + plan.n_halo)
+            self._plans[name] = plan
+        self._cols = {}
+        self.exchange = "halo"
+        return self
+
+    def halo_rows(self):
+        """(rows received per forward hop, rows received per backward hop) of this rank; an
+        all-gather receives n_nodes - n_local."""
+        return tuple(self._plans[n].n_halo for n in ("fwd", "bwd")) if self.exchange == "halo" else None
+
+    def inputs(self, x_local, which):
+        """The matrix the block `which` ("fwd" / "bwd") multiplies: this rank's rows of the layer
+        completed by the rows of the other ranks it reads."""
+        if self.exchange == "halo":
+            return self._plans[which].exchange(x_local)
+        return self.gather_rows(x_local)
 
     def local_rows(self, x_full):
         return x_full[self.lo:self.hi]
@@ -367,11 +491,11 @@ class RowShardedGraph:
         class _Hops:
             @staticmethod
             def forward(z):
-                return graph.fwd.matmul(graph.gather_rows(z))
+                return graph.fwd.matmul(graph.inputs(z, "fwd"))
 
             @staticmethod
             def backward(g):
-                return graph.bwd.matmul(graph.gather_rows(g))
+                return graph.bwd.matmul(graph.inputs(g, "bwd"))
         return _Hops
 
     def hop(self, h_local, h0_local=None, alpha=0.0, beta=1.0):

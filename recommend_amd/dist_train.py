@@ -55,7 +55,10 @@ class ShardedGraphConstructor:
     then w / (sqrt_in[src] * sqrt_in[dst]) on the local edges of both operands."""
 
     def __init__(self, rank=None, world=None, group=None, device="cuda", add_self_loops=True,
-                 normalize_adj=True, block_factory=None, normalizer=None):
+                 normalize_adj=True, block_factory=None, normalizer=None, exchange="allgather"):
+        if exchange not in ("allgather", "halo"):
+            raise ValueError(f"unknown exchange {exchange!r} (allgather, halo)")
+        self.exchange = exchange        # how a hop gets the rows of other ranks: dist.RowShardedGraph
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -111,6 +114,8 @@ class ShardedGraphConstructor:
         if feature is not None:
             raise NotImplementedError("feature-similarity edge weights are not built for the sharded graph")
         if not self.normalize_adj:
+            if self.exchange == "halo":
+                self.graph.enable_halo()
             return
         g, nz = self.graph, self.normalizer
         w_f = self._w_raw["fwd"].to(self.device)
@@ -126,6 +131,9 @@ class ShardedGraphConstructor:
         self.sqrt_in_w = sq_full[: self.num_nodes]
         g.fwd.set_values(nz.sym_scale_rows(g.fwd, w_f, self.lo, sq_full))
         g.bwd.set_values(nz.sym_scale_rows(g.bwd, w_b, self.lo, sq_full))
+        # (the normalisation reads the blocks' GLOBAL column ids; the halo plan renumbers them)
+        if self.exchange == "halo":
+            g.enable_halo()
 
     # the calls the network blocks make on the graph object
     def agg_func(self, node_x, k, f, dropout, active):
@@ -186,7 +194,7 @@ class ShardedTESTModel(nn.Module):
     rank's rows through the gather."""
 
     def __init__(self, config, user_features=None, item_features=None, rank=None, world=None, group=None,
-                 block_factory=None, normalizer=None):
+                 block_factory=None, normalizer=None, exchange="allgather"):
         super().__init__()
         if user_features:
             raise NotImplementedError("user-side features are not sharded yet")
@@ -216,7 +224,8 @@ class ShardedTESTModel(nn.Module):
                          dropout=getattr(config.model, "dropout", 0.3))
         self.graph_constructor = ShardedGraphConstructor(
             self.rank, self.world, group, device, add_self_loops=config.graph.add_self_loops,
-            normalize_adj=config.graph.normalize_adj, block_factory=block_factory, normalizer=normalizer)
+            normalize_adj=config.graph.normalize_adj, block_factory=block_factory, normalizer=normalizer,
+            exchange=exchange)
         self.emb = nn.Embedding(N, embedding_dim=emb_dim)     # registered, unused: as in the reference
         self.final_projection = nn.Linear(emb_dim, emb_dim)
         self.dropout = nn.Dropout(getattr(config.model, "dropout", 0.3))

@@ -132,6 +132,12 @@ class OracleRowBlock:
         self.n_cols = n_cols if n_cols is not None else (int(col.max()) + 1 if col.size else 1)
         self.m = sp.csr_matrix((np.asarray(val, np.float64), col, rowptr), shape=(rowptr.shape[0] - 1, self.n_cols))
 
+    def remap_columns(self, col, n_cols):
+        import scipy.sparse as sp
+        m = self.m.tocsr()
+        self.n_cols = int(n_cols)
+        self.m = sp.csr_matrix((m.data, np.asarray(col), m.indptr), shape=(m.shape[0], self.n_cols))
+
     def matmul(self, h_full, h0=None, alpha=0.0, beta=1.0):
         h = h_full.detach().numpy().astype(np.float64)[: self.n_cols]
         out = beta * (self.m @ h)
@@ -153,7 +159,7 @@ def _prop_case():
     return N, src, dst, w, x, g
 
 
-def _prop_worker(rank, world, port, q):
+def _prop_worker(rank, world, port, q, exchange="allgather"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -161,8 +167,17 @@ def _prop_worker(rank, world, port, q):
     try:
         from recommend_amd.dist import RowShardedGraph, node_range
         N, src, dst, w, x, g = _prop_case()
-        graph = RowShardedGraph(src, dst, w, N, device="cpu", block_factory=OracleRowBlock)
+        graph = RowShardedGraph(src, dst, w, N, device="cpu", block_factory=OracleRowBlock, exchange=exchange)
         assert (graph.lo, graph.hi) == node_range(N, rank, world)
+        if exchange == "halo":
+            # exactly the distinct columns outside the rank's block, and no N-row buffer
+            for which, rows, cols in (("fwd", dst, src), ("bwd", src, dst)):
+                mine = (rows >= graph.lo) & (rows < graph.hi)
+                c = cols[mine]
+                want = np.unique(c[(c < graph.lo) | (c >= graph.hi)]).shape[0]
+                assert graph._plans[which].n_halo == want, (which, graph._plans[which].n_halo, want)
+            assert graph.halo_rows() == (graph._plans["fwd"].n_halo, graph._plans["bwd"].n_halo)
+            assert not graph._gather_buf
         xl = torch.from_numpy(x[graph.lo:graph.hi]).requires_grad_(True)
         out = graph.aggrate(xl, 3, 0.2)
         out.backward(torch.from_numpy(g[graph.lo:graph.hi]))
@@ -171,12 +186,13 @@ def _prop_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_row_sharded_propagation_world2_equals_unsharded():
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
+def test_row_sharded_propagation_world2_equals_unsharded(exchange):
     import scipy.sparse as sp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prop_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_prop_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in range(2)]

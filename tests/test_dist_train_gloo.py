@@ -10,6 +10,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,6 +61,11 @@ class ScipyRowBlock:
         v = val.numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
         self.m = sp.csr_matrix((v.astype(np.float64), self.col, self.rowptr),
                                shape=(self.rowptr.shape[0] - 1, self.n_cols))
+
+    def remap_columns(self, col, n_cols):
+        import scipy.sparse as sp
+        self.col, self.n_cols = np.asarray(col), int(n_cols)
+        self.m = sp.csr_matrix((self.m.data, self.col, self.rowptr), shape=(self.rowptr.shape[0] - 1, self.n_cols))
 
     def matmul(self, h_full, h0=None, alpha=0.0, beta=1.0):
         out = beta * (self.m @ h_full.detach().numpy().astype(np.float64)[: self.n_cols])
@@ -148,7 +154,7 @@ def make_reference_state():
     return state, m.alphas.detach().clone(), m._first_emb.detach().clone()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="allgather"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -158,7 +164,7 @@ def _worker(rank, world, port, q):
         from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
         users, items, ratings, feats, batch = case()
         state, alphas, first = make_reference_state()
-        model = ShardedTESTModel(Cfg, {}, feats, block_factory=ScipyRowBlock, normalizer=NumpyNormalizer)
+        model = ShardedTESTModel(Cfg, {}, feats, block_factory=ScipyRowBlock, normalizer=NumpyNormalizer, exchange=exchange)
         model.load_state_dict(state)
         with torch.no_grad():
             model.alphas.copy_(alphas)
@@ -169,6 +175,7 @@ def _worker(rank, world, port, q):
         idx = np.flatnonzero(mine)
         model.build_graph((users[idx], items[idx], ratings[idx]), index=idx, n_total=len(users))
         model.creat_feature_weight()
+        assert model.graph_constructor.graph.exchange == exchange
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=LR)
         step = ShardedTrainStep(model, opt, gather_dot_loss, max_grad_norm=1.0)
@@ -182,7 +189,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_training_step_world2_equals_single_process():
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
+def test_sharded_training_step_world2_equals_single_process(exchange):
     from oracle import graph_oracle, loss_oracle, mmfcn_oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -190,7 +198,7 @@ def test_sharded_training_step_world2_equals_single_process():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]

@@ -26,7 +26,7 @@ def _case():
     return N, src, dst, w, x, g
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="allgather"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     try:
         from recommend_amd.dist import RowShardedGraph
         N, src, dst, w, x, g = _case()
-        graph = RowShardedGraph(src, dst, w, N, device="cuda:0")
+        graph = RowShardedGraph(src, dst, w, N, device="cuda:0", exchange=exchange)
         xl = torch.from_numpy(x[graph.lo:graph.hi]).to("cuda:0").requires_grad_(True)
         out = graph.aggrate(xl, 2, 0.1)
         out.backward(torch.from_numpy(g[graph.lo:graph.hi]).to("cuda:0"))
@@ -44,7 +44,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_row_sharded_propagation_on_the_hip_kernels():
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
+def test_row_sharded_propagation_on_the_hip_kernels(exchange):
     import scipy.sparse as sp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -52,7 +53,7 @@ def test_row_sharded_propagation_on_the_hip_kernels():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]
@@ -122,7 +123,7 @@ def _single_process_step():
     return model, {k: v.to("cuda:0") for k, v in batch.items()}, gather_dot_bpr_loss
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, exchange="allgather"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -131,7 +132,7 @@ def _train_worker(rank, world, port, q):
         from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
         full, batch, loss_fn = _single_process_step()      # only its parameters are used here
         users, items, ratings, feats, _ = _train_case()
-        model = ShardedTESTModel(_Cfg, {}, feats).to("cuda:0")
+        model = ShardedTESTModel(_Cfg, {}, feats, exchange=exchange).to("cuda:0")
         model.load_replicated_state(full)
         U = _Cfg.data.num_users
         mine = (((users >= model.lo) & (users < model.hi)) | ((items + U >= model.lo) & (items + U < model.hi)))
@@ -150,7 +151,8 @@ def _train_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_training_step_on_the_hip_kernels_equals_single_process():
+@pytest.mark.parametrize("exchange", ["allgather", "halo"])
+def test_sharded_training_step_on_the_hip_kernels_equals_single_process(exchange):
     """Two ranks (rows of the graph and of every node matrix sharded, batch split) against the
     single-process step on the same kernels: loss, clipping norm, every gradient, the parameters
     after one Adam step.  Dropout is off (the ranks' masks are drawn per local row)."""
@@ -160,7 +162,7 @@ def test_sharded_training_step_on_the_hip_kernels_equals_single_process():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(2)]
