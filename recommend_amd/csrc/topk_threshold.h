@@ -193,15 +193,23 @@ struct StreamState {
 //
 // What bounds these passes (Elec, 192k users, one slice, counters in profiles/): per SIMD the
 // vector ALU is busy 1.45 M cycles and the matrix pipe 1.48 M of a 3.5 M-cycle launch, and hardly
-// ever together (0.3 M): each wavefront issues its eight MFMAs in a burst, and what overlaps is
-// what co-resident wavefronts happen to supply.  Placing the previous tile's vector work between
-// the MFMAs (second accumulator set, fragments a tile ahead) was built and ran no faster.
+// ever together (0.3 M).  Issue is in order: a wavefront that issues its eight MFMAs in a burst
+// and then its vector work gets the SUM of the two even with three wavefronts per SIMD, and only
+// vector instructions that stand between the MFMAs in program order run in their shadow
+// (tools/mfma_valu_probe.hip: 8 MFMAs + 32 v_max per round, three wavefronts per SIMD: 343 ticks
+// per round one after the other, 245 = the matrix pipe's time interleaved; at two wavefronts per
+// SIMD, which a second accumulator set costs pass A, the interleaved form is no faster than the
+// plain one at three).  Pass B was built that way at three wavefronts per SIMD (second accumulator
+// set, half swap / group maxima / compares between the k-blocks of the next tile, visiting only
+// groups that hold a candidate): correct, and slower, 2.3 -> 3.1 ms at Elec -- 156 vector
+// instructions per wave-tile (copies of the finished set for the visit, ~44 on average for the
+// mask path, ~30 per visit) make it bound by the vector ALU whatever overlaps.
 
 // ---------------------------------------------------------------------------------------------
 // Pass A.  strata[(user * nsplit + split) * kStrata + ...]: the running maxima of this slice, in no
 // particular order.  The maxima are kept in the MFMA's own result layout (lane l: 16 rows of the
 // tile for user col in acc_a, for user 32 + col in acc_b), so no half swap is needed; the mask bits
-// of the two users a lane holds scores of come from one v_permlane32_swap of the lanes' own bits.
+// of the two users a lane holds scores of are shuffled in from the lanes that own them.
 // Masked items count with the mask score, rows past the end of the table never (kNoItem).
 template <int DC, int NST>
 __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
@@ -264,9 +272,13 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
           if ((r & 3) + 8 * (r >> 2) >= lim) acc_a[r] = acc_b[r] = kNoItem;
       }
       if (__any(st.next_m < item0 + TI)) {
-        uint32_t ma = st.mask_bits(item0, mask_items), mb = ma;
-        // ma: bits of user col, mb: bits of user 32 + col, in every lane
-        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+        const uint32_t own = st.mask_bits(item0, mask_items);
+        // ma: bits of user col, mb: bits of user 32 + col, in every lane.  (Shuffles, not one
+        // v_permlane32_swap of two copies: written as inline assembly that instruction read its
+        // operands, just written by vector instructions, too early -- the compiler adds no wait
+        // states in front of inline assembly -- and some training items went unmasked: harmless
+        // here, where a maximum that is too high only costs candidates, but not intended.)
+        uint32_t ma = (uint32_t)__shfl((int)own, col), mb = (uint32_t)__shfl((int)own, 32 + col);
         ma >>= 4 * half;
         mb >>= 4 * half;
 #pragma unroll
