@@ -183,6 +183,14 @@ struct StreamState {
 // v_max in place (fmaxf() on values the compiler does not know to be canonical costs a second
 // v_max per operand; a NaN operand is ignored either way)
 #define RK_VMAX(dst, src) asm("v_max_f32 %0, %0, %1" : "+v"(dst) : "v"(src))
+// x = bit `pos` of `bits` set ? the mask score : x, in two instructions (sign-extended bit, bit-field
+// insert); the portable (m & K) | (~m & x) came out as five per score, 164 for a tile
+#define RK_MASK_IF_BIT(x, bits, pos)                                                              \
+  do {                                                                                            \
+    uint32_t rk_m_;                                                                               \
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(rk_m_) : "v"(bits), "n"(pos));                          \
+    asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(x) : "v"(rk_m_), "v"(kMasked));                        \
+  } while (0)
 
 // The ring both passes stream the item tiles through holds NST stages of RN tiles; NST - 1 stages
 // are in flight while one is consumed.  Before a stage is read every wavefront waits for its own
@@ -283,10 +291,11 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
         mb >>= 4 * half;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const uint32_t la = (uint32_t)__builtin_amdgcn_sbfe((int32_t)ma, (r & 3) + 8 * (r >> 2), 1);
-          const uint32_t lb = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mb, (r & 3) + 8 * (r >> 2), 1);
-          acc_a[r] = __uint_as_float((la & __float_as_uint(kMasked)) | (~la & __float_as_uint(acc_a[r])));
-          acc_b[r] = __uint_as_float((lb & __float_as_uint(kMasked)) | (~lb & __float_as_uint(acc_b[r])));
+          float xa = acc_a[r], xb = acc_b[r];
+          RK_MASK_IF_BIT(xa, ma, (r & 3) + 8 * (r >> 2));
+          RK_MASK_IF_BIT(xb, mb, (r & 3) + 8 * (r >> 2));
+          acc_a[r] = xa;
+          acc_b[r] = xb;
         }
       }
 #pragma unroll
@@ -449,10 +458,11 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void collect_kernel(
         const uint32_t mbits = st.mask_bits(item0, mask_items);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const uint32_t ml = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, (r & 3) + 8 * (r >> 2), 1);
-          const uint32_t mh = (uint32_t)__builtin_amdgcn_sbfe((int32_t)mbits, 4 + (r & 3) + 8 * (r >> 2), 1);
-          acc_a[r] = __uint_as_float((ml & __float_as_uint(kMasked)) | (~ml & __float_as_uint(acc_a[r])));
-          acc_b[r] = __uint_as_float((mh & __float_as_uint(kMasked)) | (~mh & __float_as_uint(acc_b[r])));
+          float xl = acc_a[r], xh = acc_b[r];
+          RK_MASK_IF_BIT(xl, mbits, (r & 3) + 8 * (r >> 2));
+          RK_MASK_IF_BIT(xh, mbits, 4 + (r & 3) + 8 * (r >> 2));
+          acc_a[r] = xl;
+          acc_b[r] = xh;
         }
       }
 #pragma unroll
