@@ -429,12 +429,17 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * in registers; any other multiple of 64, e.g. the reference's default emb_dim 256: the kernel of
  * rk_score_topk_wide_f32, which walks the width in chunks, with the mask).
  * rk_score_topk_filtered_f32 (K <= 28, D = 64 or 128; otherwise it is the exact one) first ranks
- * by fp16 scores (both tables copied to fp16, one fp16 MFMA per 16 k), keeps the K+8 best per
- * user, re-scores those candidates with the exact chain, and runs the exact kernel only for users
- * whose result that procedure cannot certify (a candidate's fp16 score within the fp16 error bound
- * of the K-th exact score: ties at the K-th place, non-finite embeddings) and for the (at most
- * 512) users with the longest training lists, which the filter pass does not mask.
- * rk_score_topk_f32 picks between the two by size (the filter pays off from ~5*10^8 scores).
+ * by fp16 scores (both tables copied to fp16, one fp16 MFMA per 16 k), picks candidates per user
+ * -- the K+8 best by sorted lists in one pass over the scores (long item tables that one slice
+ * per user tile covers), or every item at or above a per-user threshold, the (K+8)-th largest of
+ * the maxima of 64 disjoint strata of the items, in two passes (short tables, item shards, small
+ * user blocks); RK_FILTER_FORM=lists|threshold in the environment, read at every call, forces a
+ * form --, re-scores the candidates with the exact chain, and runs the exact kernel only for
+ * users whose result that procedure cannot certify (the fp16 bound on what lies outside the
+ * candidates within the fp16 error of the K-th exact score: ties at the K-th place, non-finite
+ * embeddings, more than 64 candidates) and for the (at most 512) users with the longest training
+ * lists, which the filter passes do not mask.
+ * rk_score_topk_f32 picks between the two by size (the filter pays off from 2^27 scores).
  * All take the same workspace. */
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D,
                               int32_t K);
