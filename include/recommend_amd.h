@@ -462,6 +462,16 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users,
                                int32_t item_id_offset, float *out_scores,
                                int32_t *out_ids, void *ws, size_t ws_bytes,
                                void *stream);
+/* Diagnostic, no counterpart in the reference: how many users the LAST
+ * rk_score_topk_filtered_f32 call that used this workspace (same sizes) left to the exact
+ * kernel -- uncertified results plus the users with the longest training lists.  Waits for
+ * `stream`, then copies one counter to *open_users (host).  The results do not depend on it;
+ * the time of a call does: a filter whose thresholds are too weak still returns the exact
+ * kernel's bits, only slowly, and this number is how the tests notice.  0 is written if the
+ * call took the exact path (K > 28, widths other than 64/128). */
+int rk_score_topk_open_users(int32_t n_users, int32_t n_items, int32_t D,
+                             int32_t K, const void *ws, size_t ws_bytes,
+                             void *stream, int32_t *open_users);
 /* Merge P candidate lists per user (each Kin long, in any order, P * Kin <= 1024;
  * padding entries have id < 0) into the best K by (score desc, id asc).  Used for
  * the item slices inside one GPU and for the per-GPU lists of a user slice after

@@ -126,6 +126,7 @@ SIGNATURES = {
                                           P, P, P, c_size_t, P]),
     "rk_score_topk_filtered_f32": (c_int32, [P, c_int32, P, c_int32, c_int32, P, P, c_int32, c_int32,
                                              P, P, P, c_size_t, P]),
+    "rk_score_topk_open_users": (c_int32, [c_int32, c_int32, c_int32, c_int32, P, c_size_t, P, P]),
     "rk_topk_merge_f32": (c_int32, [P, P, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     "rk_rows_topk_ws_bytes": (c_size_t, [c_int32, c_int32]),
     "rk_score_topk_wide_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -198,6 +198,80 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
   }
 }
 
+// The merge of the compacted launch: up to 256 sorted lists per listed user (its many short item
+// slices), one wavefront per user, one level.  The lists go to LDS; every lane keeps the heads of
+// up to four lists, and each of K rounds takes the largest head of the wavefront -- a 64-bit key,
+// (score, then the smaller id), reduced by shuffles -- whose lane writes it out and moves on in that
+// list.  Padding (id < 0) ends a list.  (The bisection merges above, in two levels of 16 lists, took
+// 41 us for 48 lists and 89 us for 256: chains of dependent LDS reads behind ~100-cycle compares.)
+constexpr int kHeadsMaxLists = 256;
+__device__ __forceinline__ unsigned long long head_key(float s, int32_t id) {
+  if (id < 0) return 0ull;
+  uint32_t u = __float_as_uint(s == 0.0f ? 0.0f : s);          // (-0 and +0 tie, as they compare)
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);             // order of the floats as unsigned
+  return ((unsigned long long)u << 32) | (uint32_t)(0x7FFFFFFF - id);
+}
+__global__ __launch_bounds__(64) void topk_merge_heads_kernel(
+    const float *__restrict__ scores, const int32_t *__restrict__ ids, int32_t n_rows, int32_t P, int32_t Kin,
+    int32_t K, const int32_t *__restrict__ skip, const int32_t *__restrict__ user_list,
+    const int32_t *__restrict__ user_count, int32_t gate_cap, float *__restrict__ out_s,
+    int32_t *__restrict__ out_id) {
+  const int lane = threadIdx.x, n = P * Kin;
+  float *ls = merge_lds;
+  int32_t *li = reinterpret_cast<int32_t *>(ls + n);
+  for (int32_t pos = blockIdx.x; pos < n_rows; pos += gridDim.x) {
+    int32_t user;
+    if (!merge_row(n_rows, skip, user_list, user_count, gate_cap, 1, pos, user)) continue;
+    merge_sync<4>();                  // the row before is done with the buffer
+    for (int c = lane; c < n; c += 64) {
+      ls[c] = scores[(int64_t)pos * n + c];
+      li[c] = ids[(int64_t)pos * n + c];
+    }
+    merge_sync<4>();
+    int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    for (int r = 0; r < K; ++r) {
+      unsigned long long best = 0;
+      int bt = 0, be = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int q = lane + 64 * t, h = t == 0 ? h0 : t == 1 ? h1 : t == 2 ? h2 : h3;
+        if (q < P && h < Kin) {
+          const int e = q * Kin + h;
+          const unsigned long long key = head_key(ls[e], li[e]);
+          if (key > best) {
+            best = key;
+            bt = t;
+            be = e;
+          }
+        }
+      }
+      unsigned long long m = best;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)m, off), hi = __shfl_xor((uint32_t)(m >> 32), off);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        m = o > m ? o : m;
+      }
+      if (m == 0) {                   // every list is used up: the rest of the row is padding
+        for (int j = r + lane; j < K; j += 64) {
+          out_s[(int64_t)user * K + j] = -INFINITY;
+          out_id[(int64_t)user * K + j] = -1;
+        }
+        break;
+      }
+      const unsigned long long owners = __ballot(best == m);   // (ids are distinct: one lane)
+      if (lane == __builtin_ctzll(owners)) {
+        out_s[(int64_t)user * K + r] = ls[be];
+        out_id[(int64_t)user * K + r] = li[be];
+        h0 += bt == 0;
+        h1 += bt == 1;
+        h2 += bt == 2;
+        h3 += bt == 3;
+      }
+    }
+  }
+}
+
 // Rankings longer than one list (32 < K <= kMaxK) are produced a page of kPage places at a time:
 // page p is the kPage best among the items that rank strictly after the last entry of page p - 1.
 // This kernel files a finished page (n_rows x kPage, local ids) under columns col0.. of the
@@ -464,6 +538,13 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
 #undef RK_EXACT_CASE
   if (rc != RK_OK) return rc;
   const int32_t rpu = sel.list != nullptr ? 1 : 0;
+  if (rpu == 1 && nsplit > 1 && nsplit <= kHeadsMaxLists) {   // the compacted launch: one wavefront per listed user
+    const int grid = (int)std::min<int64_t>(n_users, 8 * (int64_t)cu_count());
+    topk_merge_heads_kernel<<<grid, 64, (size_t)2 * nsplit * kp * sizeof(float), st>>>(
+        ps, pi, n_users, nsplit, kp, K, sel.skip, sel.list, sel.count, sel.cap, out_scores, out_ids);
+    RK_CHECK_LAUNCH("topk_merge_heads_kernel");
+    return RK_OK;
+  }
   if (nsplit <= kMergeGroup) return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, rpu, out_scores, out_ids, st);
   // many lists (the compacted launch): groups of kMergeGroup lists first.  The bisection merge costs
   // lists x entries per row: 48 lists in one go took 0.7 ms for a few hundred rows.
@@ -641,6 +722,20 @@ extern "C" {
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
   if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > kMaxK) return 0;
   return topk_workspace(n_users, n_items, D, K).total;
+}
+
+int rk_score_topk_open_users(int32_t n_users, int32_t n_items, int32_t D, int32_t K, const void *ws,
+                             size_t ws_bytes, void *stream, int32_t *open_users) {
+  RK_CHECK_ARG(ws && open_users, "null pointer");
+  RK_CHECK_ARG(n_users > 0 && n_items > 0 && D > 0 && K >= 1 && K <= kMaxK, "bad sizes");
+  *open_users = 0;
+  if (filter_len(K) == 0 || (D != 64 && D != 128)) return RK_OK;
+  const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
+  RK_CHECK_ARG(ws_bytes >= w.total, "workspace too small");
+  RK_CHECK_HIP(hipMemcpyAsync(open_users, (const char *)ws + w.open_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                              (hipStream_t)stream));
+  RK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return RK_OK;
 }
 
 int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, int32_t P,

@@ -488,8 +488,8 @@ int threshold_candidates(int kc, int D, int32_t nsplit, hipStream_t st, const fl
                          const float *Ihalf, int32_t n_items, const int32_t *mask_ptr, const int32_t *mask_items,
                          const int32_t *heavy_thresh, float *strata, float *thr, void *cand, int32_t *cnt) {
   const int grid = (int)ceil_div(n_users, UPB) * nsplit;
-  const int tgrid = (int)ceil_div(n_users, 256);
-  const int32_t per_user = nsplit * kStrata;
+  RK_CHECK_ARG(nsplit >= 1 && nsplit <= 16, "top-K filter: %d item slices (1..16)", nsplit);
+  const int tgrid = (int)ceil_div(n_users, 4 * (64 / nsplit));   // 64 / nsplit users per wavefront
   if (D != 64 && D != 128) return fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", D);
   RK_CHECK_ARG(threshold_cand_bytes(n_users, nsplit) < ((size_t)1 << 32), "top-K filter: candidate places beyond 4 GiB");
   if (D == 64)
@@ -498,13 +498,13 @@ int threshold_candidates(int kc, int D, int32_t nsplit, hipStream_t st, const fl
     strata_max_kernel<2, 2><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
   RK_CHECK_LAUNCH("strata_max_kernel");
   switch (kc) {
-    case 8: strata_threshold_kernel<8><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 12: strata_threshold_kernel<12><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 16: strata_threshold_kernel<16><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 20: strata_threshold_kernel<20><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 24: strata_threshold_kernel<24><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 28: strata_threshold_kernel<28><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
-    case 32: strata_threshold_kernel<32><<<tgrid, 256, 0, st>>>(strata, n_users, per_user, thr); break;
+    case 8: strata_threshold_kernel<8><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 12: strata_threshold_kernel<12><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 16: strata_threshold_kernel<16><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 20: strata_threshold_kernel<20><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 24: strata_threshold_kernel<24><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 28: strata_threshold_kernel<28><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 32: strata_threshold_kernel<32><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
     default: return fail(RK_ERR_UNSUPPORTED, "top-K filter: candidate list length %d not built", kc);
   }
   RK_CHECK_LAUNCH("strata_threshold_kernel");

@@ -328,18 +328,29 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
   }
 }
 
-// thr[user] = the KC-th largest of the user's per_user strata maxima (-inf if fewer are finite: every
-// item is a candidate then).  One thread per user, a sorted list of KC scores in registers.
+// thr[user] = the KC-th largest of the user's nsplit * kStrata strata maxima (-inf if fewer are finite:
+// every item is a candidate then).  One lane per user and item slice sorts the KC largest of its
+// slice's kStrata maxima into registers (reads of 256 contiguous bytes per lane).  With several slices
+// the nsplit lanes of a user sit side by side in one wavefront (64 / nsplit users per wavefront) and
+// merge their lists together: KC rounds of "the largest head of the group" by shuffles, the lane that
+// owns it moving on to its next value -- each lane reads only its own list, which sits in LDS only to
+// be indexed by the head.  (One thread per user over all slices took 84 us for 19k users x 10 slices,
+// longer than pass A: strided reads by a grid of 76 workgroups; one thread walking the heads of all
+// lists in LDS took 57 us, a chain of dependent LDS reads.)
 template <int KC>
 __global__ __launch_bounds__(256) void strata_threshold_kernel(const float *__restrict__ strata, int32_t n_users,
-                                                               int32_t per_user, float *__restrict__ thr) {
-  const int32_t user = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = user < n_users;
+                                                               int32_t nsplit, float *__restrict__ thr) {
+  __shared__ float lists[256][KC + 1];     // (odd row length: the lanes' accesses spread over the banks)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int upw = 64 / nsplit;             // users per wavefront (nsplit <= 16)
+  const int lu = lane / nsplit, sl = lane - lu * nsplit;
+  const int32_t user = (blockIdx.x * 4 + (tid >> 6)) * upw + lu;
+  const bool ok = lu < upw && user < n_users;
   float s[KC];
 #pragma unroll
   for (int j = 0; j < KC; ++j) s[j] = -INFINITY;
-  const float *p = strata + (int64_t)(ok ? user : 0) * per_user;
-  for (int32_t i = 0; i < per_user; i += 4) {
+  const float *p = strata + ((int64_t)(ok ? user : 0) * nsplit + (ok ? sl : 0)) * kStrata;
+  for (int32_t i = 0; i < kStrata; i += 4) {
     const float4 v4 = *reinterpret_cast<const float4 *>(p + i);
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -351,7 +362,31 @@ __global__ __launch_bounds__(256) void strata_threshold_kernel(const float *__re
       s[0] = fmaxf(s[0], x);
     }
   }
-  if (ok) thr[user] = s[KC - 1];
+  if (nsplit == 1) {                       // uniform: the slice's list is the user's
+    if (ok) thr[user] = s[KC - 1];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < KC; ++j) lists[tid][j] = s[j];
+  float cur = s[0], last = -INFINITY;
+  int head = 0;
+  const int base = lane - sl;              // the group's first lane
+  const uint64_t group = ((1ull << nsplit) - 1) << base;
+  for (int round = 0; round < KC; ++round) {
+    float m = cur;                         // segmented max: lane `base` ends up with the group's
+    for (int d = 1; d < nsplit; d <<= 1) {
+      const float t = __shfl_down(m, d);
+      if (sl + d < nsplit) m = fmaxf(m, t);
+    }
+    m = __shfl(m, base);
+    last = m;
+    const uint64_t owners = __ballot(cur == m) & group;
+    if (owners != 0 && lane == __builtin_ctzll(owners)) {   // (ties: one lane moves on per round)
+      ++head;
+      cur = head < KC ? lists[tid][head] : -INFINITY;
+    }
+  }
+  if (ok && sl == 0) thr[user] = last;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -134,6 +134,36 @@ def test_filtered_ranking_equals_exact_kernel(U, I, D, K, scale):
     np.testing.assert_array_equal(fs[:64].cpu().numpy(), o_s)
 
 
+@pytest.mark.parametrize("U,I,D,K", [(20000, 7000, 64, 20), (6000, 9000, 128, 10), (3000, 40000, 64, 20)])
+def test_filter_certifies_ordinary_inputs(U, I, D, K):
+    """Parity cannot see a weak filter: whatever it fails to certify the exact kernel ranks, and the
+    bits come out right, only slowly.  On ordinary inputs (Gaussian embeddings, short training
+    lists) nearly every user must be settled by the filter: the library reports how many were not."""
+    from ctypes import byref, c_int32, c_size_t
+    from recommend_amd import _ffi
+    g = torch.Generator().manual_seed(U + I)
+    ue = (torch.randn(U, D, generator=g) * 0.1).to(DEV)
+    ie = (torch.randn(I, D, generator=g) * 0.1).to(DEV)
+    rng = np.random.default_rng(I)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 10 * U), rng.integers(0, I, 10 * U), U)
+    mp, mc = dev(ptr), dev(mcols)
+    lib = _ffi.load()
+    ws_bytes = lib.rk_score_topk_ws_bytes(U, I, D, K)
+    ws = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=DEV)
+    out_s = torch.empty((U, K), dtype=torch.float32, device=DEV)
+    out_i = torch.empty((U, K), dtype=torch.int32, device=DEV)
+    _ffi.call("rk_score_topk_filtered_f32", ops.ptr(ue), c_int32(U), ops.ptr(ie), c_int32(I), c_int32(D), ops.ptr(mp),
+              ops.ptr(mc), c_int32(K), c_int32(0), ops.ptr(out_s), ops.ptr(out_i), ops.ptr(ws), c_size_t(ws.numel() * 4),
+              ops.stream_ptr(ue.device))
+    n_open = c_int32(-1)
+    _ffi.call("rk_score_topk_open_users", c_int32(U), c_int32(I), c_int32(D), c_int32(K), ops.ptr(ws),
+              c_size_t(ws.numel() * 4), ops.stream_ptr(ue.device), byref(n_open))
+    # (up to 512 users with the longest training lists always go to the exact kernel)
+    assert 0 <= n_open.value <= 512 + U // 100, n_open.value
+    es, ei = ops.score_topk(ue, ie, K, mp, mc, mode="exact")
+    assert torch.equal(out_i, ei) and torch.equal(out_s.view(torch.int32), es.view(torch.int32))
+
+
 @pytest.mark.parametrize("U,I,D,K", [(700, 3000, 256, 20), (130, 517, 192, 32), (65, 129, 320, 5)])
 def test_other_embedding_widths_take_the_chunked_kernel(U, I, D, K):
     """Widths other than 64 / 128 (the reference's default emb_dim is 256) run the kernel that walks
