@@ -135,23 +135,110 @@ __global__ __launch_bounds__(256) void to_half_rows_kernel(const float *__restri
   *reinterpret_cast<uint4 *>(out + row * D + 8 * seg) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// the documented exact score: one fmaf per product, k = 0,32,1,33,...,31,63 inside each block of
-// 64, starting from +0 (what v_mfma_f32_32x32x2_f32 computes with the exact kernel's operands)
+// The documented exact score of one candidate per lane: one fmaf per product, k = 0,32,1,33,...,
+// 31,63 inside each block of 64, starting from +0 (what v_mfma_f32_32x32x2_f32 computes with the
+// exact kernel's operands).  The chain runs in one lane, but the item rows do not come in by
+// lane: a lane reading its own 4 D-byte row touches a cache line of its own in every load
+// instruction, 64 lines per instruction, and the texture addresser takes one line per cycle
+// (counters at 192k users x ~35 candidates: it is busy 95 % of the kernel, 118 M line accesses =
+// 461 k per CU against 512 k cycles).  Here D / 4 lanes read one row side by side (two lines), 256 /
+// D rows per instruction, eight instructions = a batch of 2048 / D rows, into `rows` (this
+// wavefront's own 2048 / D rows of D + 4 floats: the padding spreads the lanes' 16-byte reads over
+// the banks); then the lanes of the batch run the chain on their rows out of LDS.
+// id < 0: no candidate in this lane (the result is -inf); candidates sit in lanes 0..n-1.
+// u: this lane's user row, in LDS.
+// This pays where every lane of the wavefront holds a candidate (refine_kernel: 266 -> 184 us at
+// 192k users x 28).  Where one wavefront serves one user with ~35 candidates (refine_wide_kernel)
+// the LDS buffer halves the wavefronts in flight and the kernel turns latency-bound: measured
+// 244 us with exact_score below against 292-313 us staged, in batches of 32 or 16 rows.
+constexpr int kStageLoads = 8, kStageBatches = 2;   // load instructions per batch; batches whose loads travel together
+__device__ __forceinline__ float staged_exact_score(const float *__restrict__ u, const float *__restrict__ Iemb,
+                                                    int D, int32_t id, int n, float *__restrict__ rows) {
+  const int lane = threadIdx.x % rk::kWave;
+  const int lpr = D / 4, rpi = rk::kWave / lpr, batch = kStageLoads * rpi, stride = D + 4;
+  const int seg = lane % lpr, sub = lane / lpr;
+  float s = -INFINITY;
+  // The loads of kStageBatches batches are issued before the first is waited for: one memory round
+  // trip per round, the batches then take their turns in the (small) LDS buffer.
+  for (int b0 = 0; b0 < n; b0 += kStageBatches * batch) {
+    float4 v[kStageBatches][kStageLoads];
+    bool have[kStageBatches][kStageLoads];
+#pragma unroll
+    for (int h = 0; h < kStageBatches; ++h) {
+      const int here = min(batch, n - b0 - h * batch);       // (<= 0: no such batch)
+#pragma unroll
+      for (int j = 0; j < kStageLoads; ++j) {
+        const int c = j * rpi + sub;                           // the row of the batch this lane helps with
+        const int32_t cid = __shfl(id, min(b0 + h * batch + c, (int)rk::kWave - 1));
+        have[h][j] = c < here && cid >= 0;
+        v[h][j] = have[h][j] ? *reinterpret_cast<const float4 *>(Iemb + (int64_t)cid * D + 4 * seg) : make_float4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < kStageBatches; ++h) {
+      const int from = b0 + h * batch, here = min(batch, n - from);
+      if (here <= 0) break;                                    // wave-uniform
+#pragma unroll
+      for (int j = 0; j < kStageLoads; ++j)
+        if (have[h][j]) *reinterpret_cast<float4 *>(rows + (j * rpi + sub) * stride + 4 * seg) = v[h][j];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wavefront's LDS writes are done
+      if (lane >= from && lane < from + here && id >= 0) {
+        const float *it = rows + (lane - from) * stride;
+        float acc = 0.0f;
+        for (int c = 0; c < D / 64; ++c)
+#pragma unroll
+          for (int m = 0; m < 32; m += 4) {
+            const float4 ia = *reinterpret_cast<const float4 *>(it + 64 * c + m);
+            const float4 ib = *reinterpret_cast<const float4 *>(it + 64 * c + 32 + m);
+            const float4 ua = *reinterpret_cast<const float4 *>(u + 64 * c + m);
+            const float4 ub = *reinterpret_cast<const float4 *>(u + 64 * c + 32 + m);
+            acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
+            acc = fmaf(ia.y, ua.y, acc); acc = fmaf(ib.y, ub.y, acc);
+            acc = fmaf(ia.z, ua.z, acc); acc = fmaf(ib.z, ub.z, acc);
+            acc = fmaf(ia.w, ua.w, acc); acc = fmaf(ib.w, ub.w, acc);
+          }
+        s = acc;
+      }
+      __builtin_amdgcn_wave_barrier();      // (the next batch overwrites the rows)
+    }
+  }
+  return s;
+}
+// floats of one wavefront's row buffer; LDS of a 4-wavefront workgroup that stages rows this way
+__host__ __device__ inline int staged_rows_floats(int D) { return kStageLoads * (256 / D) * (D + 4); }
+inline size_t staged_rows_bytes(int D) { return (size_t)4 * staged_rows_floats(D) * sizeof(float); }
+
+// The same chain for a lane that reads its own item row: the 16 loads of a block of 64 are issued
+// together (loads issued eight at a time between the fmas made four round trips of the gather).
+// u: the user's row through a wave-uniform pointer (scalar loads).
 __device__ __forceinline__ float exact_score(const float *__restrict__ u, const float *__restrict__ it, int D) {
   float acc = 0.0f;
-  for (int c = 0; c < D / 64; ++c)
-#pragma unroll 2
-    for (int m = 0; m < 32; m += 4) {
-      const float4 ia = *reinterpret_cast<const float4 *>(it + 64 * c + m);
-      const float4 ib = *reinterpret_cast<const float4 *>(it + 64 * c + 32 + m);
-      const float4 ua = *reinterpret_cast<const float4 *>(u + 64 * c + m);
-      const float4 ub = *reinterpret_cast<const float4 *>(u + 64 * c + 32 + m);
+  for (int c = 0; c < D / 64; ++c) {
+    float4 r[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r[j] = *reinterpret_cast<const float4 *>(it + 64 * c + 4 * j);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float4 ia = r[m], ib = r[8 + m];
+      const float4 ua = *reinterpret_cast<const float4 *>(u + 64 * c + 4 * m);
+      const float4 ub = *reinterpret_cast<const float4 *>(u + 64 * c + 32 + 4 * m);
       acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
       acc = fmaf(ia.y, ua.y, acc); acc = fmaf(ib.y, ub.y, acc);
       acc = fmaf(ia.z, ua.z, acc); acc = fmaf(ib.z, ub.z, acc);
       acc = fmaf(ia.w, ua.w, acc); acc = fmaf(ib.w, ub.w, acc);
     }
+  }
   return acc;
+}
+
+// (score desc, id asc) as ONE unsigned order: the float's bits made monotone (-0 and +0 tie, as
+// they compare) above the complemented id; 0 for "no entry", which nothing real ranks behind.
+__device__ __forceinline__ unsigned long long rank_key(float s, int32_t id) {
+  if (id < 0) return 0ull;
+  uint32_t u = __float_as_uint(s == 0.0f ? 0.0f : s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (uint32_t)(0x7FFFFFFF - id);
 }
 
 __device__ __forceinline__ bool ranks_before(float sa, int32_t ia, float sb, int32_t ib) {
@@ -170,6 +257,7 @@ __device__ __forceinline__ bool list_beats(float sa, int32_t ia, int ja, float s
   return sa > sb || (sa == sb && (ia < ib || (ia == ib && ja < jb)));
 }
 
+constexpr int kRefineMaxD = 128;   // widest embedding the filter is built for
 // half a wavefront per user, one lane per candidate (kc <= 32).  P = 1: cand_* holds one list of kc
 // per user.  P = 2: it holds the sorted lists of two item slices per user ([user][2][kc]), and the
 // half-wavefront first merges them to the best kc by filter score (every entry's rank = its place in
@@ -240,14 +328,23 @@ __global__ __launch_bounds__(256) void refine_kernel(
   }
   const bool valid = id >= 0;
   const bool masked = approx == kMasked;   // (a product of fp16 rows is at most D in magnitude)
-  float s = -INFINITY;
-  if (valid) s = masked ? kMasked : exact_score(Uemb + (int64_t)user * D, Iemb + (int64_t)id * D, D);
+  // the user's row: loaded once by the half-wavefront (a float4 per lane) into LDS, read from there
+  // by every lane at the same address (each lane loading it for itself doubled the kernel's L1 traffic)
+  __shared__ float4 urow[8][kRefineMaxD / 4];
+  for (int j = l32; j < D / 4; j += 32)
+    urow[wave * 2 + sub][j] = user_ok ? *reinterpret_cast<const float4 *>(Uemb + (int64_t)user * D + 4 * j) : make_float4(0, 0, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): this wavefront's LDS writes are done
+  extern __shared__ float4 staged_rows[];
+  float s = staged_exact_score(reinterpret_cast<const float *>(urow[wave * 2 + sub]), Iemb, D, valid && !masked ? id : -1,
+                               rk::kWave, reinterpret_cast<float *>(staged_rows) + wave * staged_rows_floats(D));
+  if (valid && masked) s = kMasked;
   // rank among the candidates by (score desc, id asc); ids are distinct
+  const unsigned long long key = rank_key(s, id);
   int rank = 0;
   for (int l = 0; l < kc; ++l) {
-    const float sl = __shfl(s, l, 32);
-    const int32_t il = __shfl(id, l, 32);
-    rank += ranks_before(sl, il, s, id) ? 1 : 0;
+    const uint32_t hi = __shfl((uint32_t)(key >> 32), l, 32), lo = __shfl((uint32_t)key, l, 32);
+    rank += (((unsigned long long)hi << 32) | lo) > key ? 1 : 0;
   }
   if (valid && rank < K) {
     out_s[(int64_t)user * K + rank] = s;
@@ -304,8 +401,8 @@ __global__ __launch_bounds__(256) void refine_wide_kernel(
     float *__restrict__ out_s, int32_t *__restrict__ out_id, int32_t *__restrict__ done,
     int32_t *__restrict__ open_count, int32_t *__restrict__ open_list, int32_t open_cap) {
   const int wave = threadIdx.x / rk::kWave, lane = threadIdx.x % rk::kWave;
-  const int32_t user = blockIdx.x * 4 + wave;
-  if (user >= n_users) return;   // wave-uniform
+  const int32_t user = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);   // (uniform: the user's row comes by scalar loads)
+  if (user >= n_users) return;
   int32_t total = 0;
   bool over = false;
   int64_t my_place = -1;
@@ -328,15 +425,15 @@ __global__ __launch_bounds__(256) void refine_wide_kernel(
     id = (int32_t)e.y;
   }
   const bool masked = approx == kMasked;   // (a product of fp16 rows is at most D in magnitude)
+  const int n = __builtin_amdgcn_readfirstlane(min(total, (int32_t)rk::kWave));
   float s = -INFINITY;
   if (valid) s = masked ? kMasked : exact_score(Uemb + (int64_t)user * D, Iemb + (int64_t)id * D, D);
   // rank among the candidates by (score desc, id asc); ids are distinct
-  const int n = __builtin_amdgcn_readfirstlane(min(total, (int32_t)rk::kWave));
+  const unsigned long long key = rank_key(s, valid ? id : -1);
   int rank = 0;
   for (int l = 0; l < n; ++l) {
-    const float sl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), l));
-    const int32_t il = __builtin_amdgcn_readlane(id, l);
-    rank += (sl > s || (sl == s && il < id)) ? 1 : 0;
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(key >> 32), l), lo = __builtin_amdgcn_readlane((int)key, l);
+    rank += (((unsigned long long)hi << 32) | lo) > key ? 1 : 0;
   }
   if (valid && rank < K) {
     out_s[(int64_t)user * K + rank] = s;
@@ -477,7 +574,8 @@ int refine_candidates(const float *Uemb, const float *Iemb, int32_t n_users, int
                       const int32_t *uexp, const float *istats, int32_t item_id_offset, float *out_s,
                       int32_t *out_id, int32_t *done, int32_t *open_count, int32_t *open_list,
                       int32_t open_cap, hipStream_t st) {
-  refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, 0, st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, P, kc, K,
+  RK_CHECK_ARG(D % 64 == 0 && D <= kRefineMaxD, "top-K filter: embedding width %d not built (64/128)", D);
+  refine_kernel<<<(unsigned)ceil_div(n_users, 8), 256, staged_rows_bytes(D), st>>>(Uemb, Iemb, n_users, n_items, D, cand_s, cand_id, P, kc, K,
                                                                  mask_ptr, heavy_thresh, unorm, uexp, istats, item_id_offset, out_s, out_id, done,
                                                                  open_count, open_list, open_cap);
   RK_CHECK_LAUNCH("refine_kernel");
