@@ -331,10 +331,15 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
 #pragma unroll
     for (int j = 0; j < NR; ++j) ranked[j] = j < kmax ? topk_ids[(int64_t)u * id_stride + j] : -1;
     if (n_pos <= 16) {
-      for (int32_t t = tb; t < te; ++t) {
-        const int32_t v = tgt_items[t];
+      // (four target items per round, loaded together: one at a time is a chain of up to 16 round trips)
+      for (int32_t t = tb; t < te; t += 4) {
+        int32_t v[4];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) rel[j >> 5] |= (ranked[j] == v && v >= 0 ? 1u : 0u) << (j & 31);
+        for (int e = 0; e < 4; ++e) v[e] = t + e < te ? tgt_items[t + e] : -1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) rel[j >> 5] |= (ranked[j] == v[e] && v[e] >= 0 ? 1u : 0u) << (j & 31);
       }
     } else {
       // long target lists (sorted): a bisection per ranked item
@@ -390,6 +395,10 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
 #pragma unroll
   for (int i = 0; i < MAXK * 6; ++i) {
+    if (i >= nk * 6) {                 // (uniform; a 64-bit shuffle reduction is 12 LDS-pipe instructions)
+      if (lane == 0) red[wave][i] = 0.0;
+      continue;
+    }
     double v = (double)vals[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);

@@ -159,11 +159,13 @@ class ShardedRankingEvaluator:
             _out, sums = self.compute.rank_metrics(mi, st["tgt_ptr"], st["tgt_items"], self.k_list,
                                                    mean_denominator=self.n_users, return_sums=True)
         all_reduce_tensor(sums, dist.ReduceOp.SUM, self.group)
-        table = (sums / float(self.n_users)).to(torch.float32).cpu()
+        # (on the sums' device, like RankingEvaluator.evaluate: reading a value is what synchronises)
+        table = (sums / float(self.n_users)).to(torch.float32)
         out = {}
         for ki, k in enumerate(self.k_list):
+            row = table[ki]
             for name in self.metrics:
-                out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
+                out[f"{name}@{k}"] = row[METRIC_ORDER.index(name)]
         return out
 
 
@@ -218,11 +220,13 @@ class UserShardedRankingEvaluator:
             _out, sums = self.compute.rank_metrics(ids, st["tgt_ptr"], st["tgt_items"], self.k_list,
                                                    mean_denominator=self.n_users, return_sums=True)
         all_reduce_tensor(sums, dist.ReduceOp.SUM, self.group)
-        table = (sums / float(self.n_users)).to(torch.float32).cpu()
+        # (on the sums' device, like RankingEvaluator.evaluate: reading a value is what synchronises)
+        table = (sums / float(self.n_users)).to(torch.float32)
         out = {}
         for ki, k in enumerate(self.k_list):
+            row = table[ki]
             for name in self.metrics:
-                out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
+                out[f"{name}@{k}"] = row[METRIC_ORDER.index(name)]
         return out
 
 

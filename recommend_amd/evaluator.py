@@ -105,11 +105,16 @@ class RankingEvaluator:
                 raise ValueError("k must be in the range [1, num_items]")
         st = self._device_state(user_embeddings.device)
         _scores, ids = self.topk(user_embeddings, item_embeddings, max(self.k_list))
-        table = ops.rank_metrics(ids, st["tgt_ptr"], st["tgt_items"], self.k_list).cpu()
+        # The metrics stay on the embeddings' device, as evaluate_all_at_k's do (evalue/metric.py:
+        # 157-164: means of device tensors): nothing here waits for the GPU, so a caller that
+        # evaluates again right away has its launches queued behind this call's kernels; reading a
+        # value (float(), .item(), .cpu()) is what synchronises.
+        table = ops.rank_metrics(ids, st["tgt_ptr"], st["tgt_items"], self.k_list)
         out = {}
         for ki, k in enumerate(self.k_list):
+            row = table[ki]
             for name in self.metrics:
-                out[f"{name}@{k}"] = table[ki, METRIC_ORDER.index(name)].clone()
+                out[f"{name}@{k}"] = row[METRIC_ORDER.index(name)]
         return out
 
 
