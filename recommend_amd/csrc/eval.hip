@@ -341,8 +341,40 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
 #pragma unroll
           for (int j = 0; j < NR; ++j) rel[j >> 5] |= (ranked[j] == v[e] && v[e] >= 0 ? 1u : 0u) << (j & 31);
       }
+    } else if constexpr (NW == 1) {
+      // long target lists (sorted): every ranked item bisects at the same time, so that a round is
+      // kmax independent loads (one item after the other is a chain of kmax * log2(n_pos) dependent
+      // loads in one lane -- 59 us for the whole launch at 192k users, set by its slowest wavefront)
+      int32_t lo[NR], hi[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        lo[j] = tb;
+        hi[j] = j < kmax && ranked[j] >= 0 ? te : tb;
+      }
+      const int rounds = 32 - __clz(n_pos);        // a bisection of n entries ends within floor(log2 n) + 1 steps
+      for (int s = 0; s < rounds; ++s) {
+        int32_t v[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[j] = lo[j] < hi[j] ? tgt_items[(lo[j] + hi[j]) >> 1] : 0;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int32_t mid = (lo[j] + hi[j]) >> 1;
+          if (lo[j] < hi[j]) {
+            if (v[j] < ranked[j])
+              lo[j] = mid + 1;
+            else
+              hi[j] = mid;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const bool look = j < kmax && ranked[j] >= 0 && lo[j] < te;
+        const int32_t v = look ? tgt_items[lo[j]] : -1;
+        rel[0] |= (look && v == ranked[j] ? 1u : 0u) << j;
+      }
     } else {
-      // long target lists (sorted): a bisection per ranked item
+      // (rankings of more than 32 places: a bisection per ranked item, one after the other)
 #pragma unroll 1
       for (int j = 0; j < kmax; ++j) {
         int32_t it = ranked[0];
