@@ -16,7 +16,7 @@ src, prefix = sys.argv[1], sys.argv[2]
 SPMM = ("spmm_rows_kernel",)
 TOPK = ("score_topk_kernel", "topk_merge_sorted_kernel", "topk_merge_kernel", "refine_kernel", "row_stats_kernel",
         "table_stats_kernel", "to_half_rows_kernel", "strata_max_kernel", "strata_threshold_kernel", "collect_kernel",
-        "refine_wide_kernel", "mask_hist_kernel", "heavy_thresh_kernel")
+        "refine_wide_kernel", "mask_hist_kernel", "heavy_thresh_kernel", "topk_merge_heads_kernel")
 
 
 def per_kernel(path):
