@@ -212,6 +212,11 @@ struct StreamState {
 // groups that hold a candidate): correct, and slower, 2.3 -> 3.1 ms at Elec -- 156 vector
 // instructions per wave-tile (copies of the finished set for the visit, ~44 on average for the
 // mask path, ~30 per visit) make it bound by the vector ALU whatever overlaps.
+// Without a second set -- the two chains of a tile half a phase apart, each chain's maxima folded
+// between the MFMAs of the other -- pass A was correct and slower as well (19k x 7k 46 -> 52 us,
+// 36k x 18k 124 -> 152, 24k x 63k 219 -> 268): a chain of four MFMAs on ONE accumulator issues at half
+// the pipe's rate (each waits for the one before), where the two chains of a tile issued
+// alternately keep the pipe full.
 
 // ---------------------------------------------------------------------------------------------
 // Pass A.  strata[(user * nsplit + split) * kStrata + ...]: the running maxima of this slice, in no
