@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void rows_topk_kernel(const float *__restrict_
 // One wavefront per user ranks all n = P*Kin candidates by counting how many
 // beat each one; candidates with rank < K are written to their final slot.
 constexpr int MERGE_MAX = 1024;
-constexpr int kMergeGroup = 16;   // lists per intermediate merge (16 * 32 entries <= MERGE_MAX)
 
 __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, int32_t ib, int jb) {
   const bool va = ia >= 0, vb = ib >= 0;
@@ -81,19 +80,19 @@ __device__ __forceinline__ bool beats(float sa, int32_t ia, int ja, float sb, in
 }
 
 // Which rows a merge launch works on (user_list / user_count / gate_cap as for
-// score_topk_kernel); returns false if this wavefront has nothing to do.  rows_per_user > 0 marks
-// the compacted launch, whose rows are rows_per_user per listed user (intermediate merges of groups
-// of lists; the indirection through user_list applies if it is given).
+// score_topk_kernel: with a list, row `row_in` is a position of the compacted launch and stands
+// for user user_list[row_in]); returns false if this wavefront has nothing to do.
 __device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, const int32_t *user_list,
-                                          const int32_t *user_count, int32_t gate_cap, int32_t rows_per_user,
-                                          int32_t row_in, int32_t &row_out) {
+                                          const int32_t *user_count, int32_t gate_cap, int32_t row_in,
+                                          int32_t &row_out) {
+  const bool listed = user_list != nullptr;
   if (user_count != nullptr) {
     const int32_t cnt = user_count[0];
-    if (rows_per_user > 0 ? cnt > gate_cap : cnt <= gate_cap) return false;
-    if (rows_per_user > 0) n_rows = min(n_rows, cnt * rows_per_user);
+    if (listed ? cnt > gate_cap : cnt <= gate_cap) return false;
+    if (listed) n_rows = min(n_rows, cnt);
   }
   if (row_in >= n_rows) return false;  // uniform over the lanes that share a row
-  row_out = user_list != nullptr ? user_list[row_in] : row_in;
+  row_out = listed ? user_list[row_in] : row_in;
   return skip == nullptr || skip[row_out] == 0;   // flagged rows of out are already final
 }
 
@@ -101,40 +100,32 @@ __device__ __forceinline__ bool merge_row(int32_t n_rows, const int32_t *skip, c
 // the launch (n entries per row, not MERGE_MAX): a merge lives on the number of rows in flight.
 extern __shared__ float merge_lds[];
 
-// RPW rows per workgroup: 4 = one wavefront per row (many rows), 1 = the whole workgroup on one
-// row (the few rows of the compacted launch, where one wavefront's chain of dependent LDS reads is
-// what the launch takes).  Workgroups walk the rows with a grid stride, so a launch that is gated
-// off on the device, or has few rows, does not pay for one workgroup per four rows of the table.
-template <int RPW>
+// One wavefront per row, four rows per workgroup.  Workgroups walk the rows with a grid stride, so
+// a launch that is gated off on the device does not pay for one workgroup per four rows of the table.
 __device__ __forceinline__ void merge_sync() {
-  if constexpr (RPW == 1) {
-    __syncthreads();
-  } else {
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS accesses are done
-  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS accesses are done
 }
 
-template <int RPW>
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t n, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  constexpr int LANES = 256 / RPW;
+    float *__restrict__ out_s, int32_t *__restrict__ out_id) {
+  constexpr int RPW = 4, LANES = 256 / RPW;
   const int sub_row = threadIdx.x / LANES, lane = threadIdx.x % LANES;
   float *cs_w = merge_lds + (size_t)sub_row * 2 * n;
   int32_t *ci_w = reinterpret_cast<int32_t *>(cs_w + n);
   for (int64_t rb = blockIdx.x; rb * RPW < n_users; rb += gridDim.x) {
     const int32_t pos = (int32_t)(rb * RPW) + sub_row;
     int32_t user;
-    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) continue;
-    merge_sync<RPW>();                 // the row before is done with the buffer
+    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, pos, user)) continue;
+    merge_sync();                 // the row before is done with the buffer
     for (int c = lane; c < n; c += LANES) {
       cs_w[c] = scores[(int64_t)pos * n + c];
       ci_w[c] = ids[(int64_t)pos * n + c];
     }
-    merge_sync<RPW>();
+    merge_sync();
     for (int c = lane; c < n; c += LANES) {
       const float sc = cs_w[c];
       const int32_t ic = ci_w[c];
@@ -152,13 +143,12 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
 // asc), padding last -- as the lists of score_topk_kernel and of this kernel are.  An entry is
 // beaten by the entries in front of it in its own list and by a prefix of every other list, found
 // by bisection: P * log2(Kin) steps per entry instead of P * Kin.
-template <int RPW>
 __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids,
     int32_t n_users, int32_t P, int32_t Kin, int32_t K, const int32_t *__restrict__ skip,
     const int32_t *__restrict__ user_list, const int32_t *__restrict__ user_count, int32_t gate_cap,
-    int32_t rows_per_user, float *__restrict__ out_s, int32_t *__restrict__ out_id) {
-  constexpr int LANES = 256 / RPW;
+    float *__restrict__ out_s, int32_t *__restrict__ out_id) {
+  constexpr int RPW = 4, LANES = 256 / RPW;
   const int sub_row = threadIdx.x / LANES, lane = threadIdx.x % LANES;
   const int n = P * Kin;
   float *cs_w = merge_lds + (size_t)sub_row * 2 * n;
@@ -166,13 +156,13 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
   for (int64_t rb = blockIdx.x; rb * RPW < n_users; rb += gridDim.x) {
     const int32_t pos = (int32_t)(rb * RPW) + sub_row;
     int32_t user;
-    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, rows_per_user, pos, user)) continue;
-    merge_sync<RPW>();                 // the row before is done with the buffer
+    if (!merge_row(n_users, skip, user_list, user_count, gate_cap, pos, user)) continue;
+    merge_sync();                 // the row before is done with the buffer
     for (int c = lane; c < n; c += LANES) {
       cs_w[c] = scores[(int64_t)pos * n + c];
       ci_w[c] = ids[(int64_t)pos * n + c];
     }
-    merge_sync<RPW>();
+    merge_sync();
     for (int c = lane; c < n; c += LANES) {
       const float sc = cs_w[c];
       const int32_t ic = ci_w[c];
@@ -200,16 +190,33 @@ __global__ __launch_bounds__(256) void topk_merge_sorted_kernel(
 
 // The merge of the compacted launch: up to 256 sorted lists per listed user (its many short item
 // slices), one wavefront per user, one level.  The lists go to LDS; every lane keeps the heads of
-// up to four lists, and each of K rounds takes the largest head of the wavefront -- a 64-bit key,
-// (score, then the smaller id), reduced by shuffles -- whose lane writes it out and moves on in that
-// list.  Padding (id < 0) ends a list.  (The bisection merges above, in two levels of 16 lists, took
-// 41 us for 48 lists and 89 us for 256: chains of dependent LDS reads behind ~100-cycle compares.)
+// up to four lists and, in registers, the key of the best of them: (score, then the smaller id) as
+// a pair of unsigned words.  Each of K rounds takes the largest key of the wavefront -- the larger
+// high word by a DPP reduction, then the larger low word among the lanes that hold it --, the lane
+// that owns it writes the entry out, moves on in that list and looks at its heads again.  Padding
+// (id < 0) ends a list.  (Bisection merges as above, in two levels of 16 lists with a workgroup per
+// row, took 41 us for 48 lists and 89 us for 256: chains of dependent LDS reads behind ~100-cycle
+// compares; this kernel with the key reduced by twelve dependent shuffles per round 15 and 24 us.)
 constexpr int kHeadsMaxLists = 256;
-__device__ __forceinline__ unsigned long long head_key(float s, int32_t id) {
-  if (id < 0) return 0ull;
-  uint32_t u = __float_as_uint(s == 0.0f ? 0.0f : s);          // (-0 and +0 tie, as they compare)
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);             // order of the floats as unsigned
-  return ((unsigned long long)u << 32) | (uint32_t)(0x7FFFFFFF - id);
+// max over the wavefront of an unsigned word, in every lane: shifts inside the rows of 16 lanes,
+// the row's last lane broadcast to the next row(s), the wavefront's last lane read back (a maximum
+// may count a lane twice, and 0, which a lane without a source keeps, is its identity)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// (score desc, id asc) as a pair of unsigned words: the float's bits made monotone (-0 and +0 tie,
+// as they compare; never 0 for a score that can be listed), and the complemented id; (0, 0): no entry
+__device__ __forceinline__ void head_key(float s, int32_t id, uint32_t &hi, uint32_t &lo) {
+  uint32_t u = __float_as_uint(s == 0.0f ? 0.0f : s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  hi = id < 0 ? 0u : u;
+  lo = id < 0 ? 0u : (uint32_t)(0x7FFFFFFF - id);
 }
 __global__ __launch_bounds__(64) void topk_merge_heads_kernel(
     const float *__restrict__ scores, const int32_t *__restrict__ ids, int32_t n_rows, int32_t P, int32_t Kin,
@@ -221,52 +228,53 @@ __global__ __launch_bounds__(64) void topk_merge_heads_kernel(
   int32_t *li = reinterpret_cast<int32_t *>(ls + n);
   for (int32_t pos = blockIdx.x; pos < n_rows; pos += gridDim.x) {
     int32_t user;
-    if (!merge_row(n_rows, skip, user_list, user_count, gate_cap, 1, pos, user)) continue;
-    merge_sync<4>();                  // the row before is done with the buffer
+    if (!merge_row(n_rows, skip, user_list, user_count, gate_cap, pos, user)) continue;
+    merge_sync();                  // the row before is done with the buffer
     for (int c = lane; c < n; c += 64) {
       ls[c] = scores[(int64_t)pos * n + c];
       li[c] = ids[(int64_t)pos * n + c];
     }
-    merge_sync<4>();
+    merge_sync();
     int h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-    for (int r = 0; r < K; ++r) {
-      unsigned long long best = 0;
-      int bt = 0, be = 0;
+    uint32_t best_hi = 0, best_lo = 0;
+    int bt = 0, be = 0;
+    auto look = [&]() {            // the best of this lane's heads
+      best_hi = best_lo = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int q = lane + 64 * t, h = t == 0 ? h0 : t == 1 ? h1 : t == 2 ? h2 : h3;
         if (q < P && h < Kin) {
           const int e = q * Kin + h;
-          const unsigned long long key = head_key(ls[e], li[e]);
-          if (key > best) {
-            best = key;
+          uint32_t hi, lo;
+          head_key(ls[e], li[e], hi, lo);
+          if (hi > best_hi || (hi == best_hi && lo > best_lo)) {
+            best_hi = hi;
+            best_lo = lo;
             bt = t;
             be = e;
           }
         }
       }
-      unsigned long long m = best;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)m, off), hi = __shfl_xor((uint32_t)(m >> 32), off);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        m = o > m ? o : m;
-      }
-      if (m == 0) {                   // every list is used up: the rest of the row is padding
+    };
+    look();
+    for (int r = 0; r < K; ++r) {
+      const uint32_t m_hi = wave_max_u32(best_hi);
+      if (m_hi == 0) {                // every list is used up: the rest of the row is padding
         for (int j = r + lane; j < K; j += 64) {
           out_s[(int64_t)user * K + j] = -INFINITY;
           out_id[(int64_t)user * K + j] = -1;
         }
         break;
       }
-      const unsigned long long owners = __ballot(best == m);   // (ids are distinct: one lane)
-      if (lane == __builtin_ctzll(owners)) {
+      const uint32_t m_lo = wave_max_u32(best_hi == m_hi ? best_lo : 0u);
+      if (best_hi == m_hi && best_lo == m_lo) {   // (ids are distinct: one lane)
         out_s[(int64_t)user * K + r] = ls[be];
         out_id[(int64_t)user * K + r] = li[be];
         h0 += bt == 0;
         h1 += bt == 1;
         h2 += bt == 2;
         h3 += bt == 3;
+        look();
       }
     }
   }
@@ -524,32 +532,19 @@ struct UserSel {   // which users a launch works on; see score_topk_kernel and m
 };
 
 // sorted_lists: every list is in (score desc, id asc) order already, padding last.
-// rows_per_user: see merge_row (0 unless this is an intermediate or final merge of the compacted
-// launch).
 int merge_lists(const float *scores, const int32_t *ids, int32_t n_users, int32_t P, int32_t Kin,
-                int32_t K, const UserSel &sel, bool sorted_lists, int32_t rows_per_user, float *out_scores,
-                int32_t *out_ids, hipStream_t st) {
+                int32_t K, const UserSel &sel, bool sorted_lists, float *out_scores, int32_t *out_ids, hipStream_t st) {
   RK_CHECK_ARG((int64_t)P * Kin <= MERGE_MAX, "too many candidates per user (%lld > %d)",
                (long long)P * Kin, MERGE_MAX);
   RK_CHECK_ARG(K <= P * Kin, "K larger than the candidate count");
-  // the compacted launch has few rows (a whole workgroup each); everything else a wavefront per row
-  const int rpw = rows_per_user > 0 ? 1 : 4;
-  const int grid = (int)std::min<int64_t>(rk::ceil_div(n_users, rpw), 8 * (int64_t)cu_count());
-  const size_t lds = (size_t)rpw * 2 * P * Kin * sizeof(float);
-  // (measured on the compacted launch's 16 x 20 entries per row: bisection 34 us per launch,
-  // counting all pairs with the whole workgroup 55 us -- a compare is ~100 cycles of branches)
-  if (sorted_lists && rpw == 1)
-    topk_merge_sorted_kernel<1><<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
-                                                      sel.cap, rows_per_user, out_scores, out_ids);
-  else if (sorted_lists)
-    topk_merge_sorted_kernel<4><<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count,
-                                                      sel.cap, rows_per_user, out_scores, out_ids);
-  else if (rpw == 1)
-    topk_merge_kernel<1><<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
-                                               sel.cap, rows_per_user, out_scores, out_ids);
+  const int grid = (int)std::min<int64_t>(rk::ceil_div(n_users, 4), 8 * (int64_t)cu_count());
+  const size_t lds = (size_t)4 * 2 * P * Kin * sizeof(float);
+  if (sorted_lists)
+    topk_merge_sorted_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P, Kin, K, sel.skip, sel.list, sel.count, sel.cap,
+                                                   out_scores, out_ids);
   else
-    topk_merge_kernel<4><<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count,
-                                               sel.cap, rows_per_user, out_scores, out_ids);
+    topk_merge_kernel<<<grid, 256, lds, st>>>(scores, ids, n_users, P * Kin, K, sel.skip, sel.list, sel.count, sel.cap,
+                                            out_scores, out_ids);
   RK_CHECK_LAUNCH("topk_merge_kernel");
   return RK_OK;
 }
@@ -578,25 +573,15 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
   }
 #undef RK_EXACT_CASE
   if (rc != RK_OK) return rc;
-  const int32_t rpu = sel.list != nullptr ? 1 : 0;
-  if (rpu == 1 && nsplit > 1 && nsplit <= kHeadsMaxLists) {   // the compacted launch: one wavefront per listed user
-    const int grid = (int)std::min<int64_t>(n_users, 8 * (int64_t)cu_count());
-    topk_merge_heads_kernel<<<grid, 64, (size_t)2 * nsplit * kp * sizeof(float), st>>>(
+  if (sel.list != nullptr) {   // the compacted launch: one wavefront per listed user, any number of slices up to 256
+    RK_CHECK_ARG(nsplit <= kHeadsMaxLists, "compacted launch: %d item slices (at most %d)", nsplit, kHeadsMaxLists);
+    const int mgrid = (int)std::min<int64_t>(n_users, 8 * (int64_t)cu_count());
+    topk_merge_heads_kernel<<<mgrid, 64, (size_t)2 * nsplit * kp * sizeof(float), st>>>(
         ps, pi, n_users, nsplit, kp, K, sel.skip, sel.list, sel.count, sel.cap, out_scores, out_ids);
     RK_CHECK_LAUNCH("topk_merge_heads_kernel");
     return RK_OK;
   }
-  if (nsplit <= kMergeGroup) return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, rpu, out_scores, out_ids, st);
-  // many lists (the compacted launch): groups of kMergeGroup lists first.  The bisection merge costs
-  // lists x entries per row: 48 lists in one go took 0.7 ms for a few hundred rows.
-  const int groups = nsplit / kMergeGroup;   // open_nsplit() makes this exact
-  float *gs = (float *)(pi + (size_t)n_users * nsplit * kp);
-  int32_t *gi = (int32_t *)(gs + (size_t)n_users * groups * kp);
-  UserSel rows = sel;
-  rows.list = nullptr;
-  if ((rc = merge_lists(ps, pi, n_users * groups, kMergeGroup, kp, kp, rows, true, groups, gs, gi, st)) != RK_OK)
-    return rc;
-  return merge_lists(gs, gi, n_users, groups, kp, K, sel, true, 1, out_scores, out_ids, st);
+  return merge_lists(ps, pi, n_users, nsplit, kp, K, sel, true, out_scores, out_ids, st);
 }
 
 // Users the filter could not certify are few (ties at the K-th place, degenerate embeddings).
@@ -607,14 +592,11 @@ constexpr int kOpenCap = 1024;
 inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpenCap, rk::ceil_div(n_users, UPB) * UPB); }
 inline int open_nsplit(int32_t n_items, int32_t K) {
   const int64_t tiles = rk::ceil_div(n_items, TI);
-  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(256, tiles / 4));
-  if (want <= kMergeGroup) return (int)want;               // one merge
-  return (int)(want / kMergeGroup * kMergeGroup);          // two: whole groups
+  return (int)std::max<int64_t>(1, std::min<int64_t>(kHeadsMaxLists, tiles / 4));
 }
-// floats + ints of the compacted launch: its partial lists and the intermediate merge results
+// floats + ints of the compacted launch: its partial lists
 inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
-  const size_t ns = (size_t)open_nsplit(n_items, K);
-  return (size_t)open_positions(n_users) * (ns + ns / kMergeGroup + 1) * kpad_for(K);
+  return (size_t)open_positions(n_users) * ((size_t)open_nsplit(n_items, K) + 1) * kpad_for(K);
 }
 
 // candidate list length of the filter pass for a final K (0: no filter pass, K too large)
@@ -784,7 +766,7 @@ int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users, 
   RK_CHECK_ARG(n_users >= 0 && P > 0 && Kin > 0 && K > 0, "bad sizes");
   if (n_users == 0) return RK_OK;
   RK_CHECK_ARG(scores && ids && out_scores && out_ids, "null pointer");
-  return merge_lists(scores, ids, n_users, P, Kin, K, UserSel{}, false, 0, out_scores, out_ids, (hipStream_t)stream);
+  return merge_lists(scores, ids, n_users, P, Kin, K, UserSel{}, false, out_scores, out_ids, (hipStream_t)stream);
 }
 
 int rk_score_topk_exact_f32(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_items,
@@ -880,7 +862,7 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
   // two slices: the refine kernel merges the two lists itself; more: a merge launch first
   const bool merge_in_refine = !direct && fsplit == 2 && n_items >= kc;
   if (!direct && !merge_in_refine &&
-      (rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, 0, cand_s, cand_id, st)) != RK_OK)
+      (rc = merge_lists(ps, pi, n_users, fsplit, kc, std::min(kc, n_items), UserSel{}, true, cand_s, cand_id, st)) != RK_OK)
     return rc;
   // 3. exact scores of the candidates, final order, certification
   if ((rc = rk::refine_candidates(Uemb, Iemb, n_users, n_items, D, merge_in_refine ? ps : cand_s,

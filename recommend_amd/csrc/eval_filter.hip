@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void refine_kernel(
   // rank among the candidates by (score desc, id asc); ids are distinct
   const unsigned long long key = rank_key(s, id);
   int rank = 0;
-  for (int l = 0; l < kc; ++l) {
+  // (all 32 lanes of the half, unrolled: lanes past kc hold key 0, and the shuffles of a loop with
+  // a run-time trip count are waited for one pair at a time)
+#pragma unroll
+  for (int l = 0; l < 32; ++l) {
     const uint32_t hi = __shfl((uint32_t)(key >> 32), l, 32), lo = __shfl((uint32_t)key, l, 32);
     rank += (((unsigned long long)hi << 32) | lo) > key ? 1 : 0;
   }
