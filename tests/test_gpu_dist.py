@@ -1,5 +1,8 @@
-"""Two ranks (gloo rendezvous, both on cuda:0) run the row-sharded propagation on the HIP SpMM
-kernels; forward and gradient must equal the float64 result of the unsharded recurrence."""
+"""The sharded paths on the HIP kernels: two ranks with a gloo rendezvous (both on cuda:0, the
+collectives through host memory), and one rank on the RCCL backend ("nccl"; a one-GPU box holds
+no second rank) so that the device-side branches of every collective in dist.py run under test.
+Forward and gradient must equal the float64 result of the unsharded recurrence; the sharded
+training step and the sharded evaluators must equal their single-process counterparts."""
 import os
 import socket
 import sys
@@ -26,11 +29,45 @@ def _case():
     return N, src, dst, w, x, g
 
 
-def _worker(rank, world, port, q, exchange="allgather"):
+BACKENDS = [("gloo", 2), ("nccl", 1)]
+
+
+def _init(backend, rank, world, port):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(target, world, *args, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def _worker(rank, world, port, q, exchange="allgather", backend="gloo"):
+    _init(backend, rank, world, port)
     try:
         from recommend_amd.dist import RowShardedGraph
         N, src, dst, w, x, g = _case()
@@ -44,22 +81,11 @@ def _worker(rank, world, port, q, exchange="allgather"):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend,world", BACKENDS)
 @pytest.mark.parametrize("exchange", ["allgather", "halo"])
-def test_row_sharded_propagation_on_the_hip_kernels(exchange):
+def test_row_sharded_propagation_on_the_hip_kernels(exchange, backend, world):
     import scipy.sparse as sp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=240) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run(_worker, world, exchange, backend, timeout=240)
     N, src, dst, w, x, g = _case()
     A = sp.csr_matrix((w.astype(np.float64), (dst, src)), shape=(N, N))
     h0 = x.astype(np.float64)
@@ -72,7 +98,7 @@ def test_row_sharded_propagation_on_the_hip_kernels(exchange):
         gx += 0.1 * gh
         gh = 0.9 * (A.T @ gh)
     gx += gh
-    assert sorted((lo, hi) for _r, lo, hi, _o, _g in results) == [(0, 1501), (1501, 3001)]
+    assert sorted((lo, hi) for _r, lo, hi, _o, _g in results) == ([(0, 1501), (1501, 3001)] if world == 2 else [(0, 3001)])
     for _rank, lo, hi, out, grad in results:
         assert np.abs(out - h[lo:hi]).max() <= 1e-5 * np.abs(h).max()
         assert np.abs(grad - gx[lo:hi]).max() <= 1e-5 * np.abs(gx).max()
@@ -123,11 +149,8 @@ def _single_process_step():
     return model, {k: v.to("cuda:0") for k, v in batch.items()}, gather_dot_bpr_loss
 
 
-def _train_worker(rank, world, port, q, exchange="allgather"):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _train_worker(rank, world, port, q, exchange="allgather", backend="gloo"):
+    _init(backend, rank, world, port)
     try:
         from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
         full, batch, loss_fn = _single_process_step()      # only its parameters are used here
@@ -151,24 +174,13 @@ def _train_worker(rank, world, port, q, exchange="allgather"):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend,world", BACKENDS)
 @pytest.mark.parametrize("exchange", ["allgather", "halo"])
-def test_sharded_training_step_on_the_hip_kernels_equals_single_process(exchange):
-    """Two ranks (rows of the graph and of every node matrix sharded, batch split) against the
+def test_sharded_training_step_on_the_hip_kernels_equals_single_process(exchange, backend, world):
+    """The ranks (rows of the graph and of every node matrix sharded, batch split) against the
     single-process step on the same kernels: loss, clipping norm, every gradient, the parameters
     after one Adam step.  Dropout is off (the ranks' masks are drawn per local row)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=300) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run(_train_worker, world, exchange, backend)
     model, batch, loss_fn = _single_process_step()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     loss = loss_fn(model(batch), batch)
@@ -197,5 +209,55 @@ def test_sharded_training_step_on_the_hip_kernels_equals_single_process(exchange
             assert float(np.abs(params[name] - new).max()) <= 1e-5 * float(np.abs(new).max()) + 2e-5, (rank, name)
             checked += 1
         assert checked >= 20
-    for name in results[0][4]:
-        assert np.array_equal(results[0][4][name], results[1][4][name]), name
+    for other in results[1:]:
+        for name in results[0][4]:
+            assert np.array_equal(results[0][4][name], other[4][name]), name
+
+
+# ---------------------------------------------------------------- sharded evaluation
+METRICS = ["precision", "recall", "hit_rate", "ndcg", "map", "mrr"]
+
+
+def _eval_case():
+    rng = np.random.default_rng(5)
+    U, I, D = 2500, 3001, 64
+    ue = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
+    ie = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
+    tr = np.unique(np.stack([rng.integers(0, U, 20000), rng.integers(0, I, 20000)], 1), axis=0)
+    va = np.unique(np.stack([rng.integers(0, U, 5000), rng.integers(0, I, 5000)], 1), axis=0)
+    return U, I, ue, ie, tr, va
+
+
+def _eval_worker(rank, world, port, q, backend="gloo"):
+    _init(backend, rank, world, port)
+    try:
+        from recommend_amd.dist import ShardedRankingEvaluator, UserShardedRankingEvaluator
+        U, I, ue, ie, tr, va = _eval_case()
+        ue_d, ie_d = torch.from_numpy(ue).to("cuda:0"), torch.from_numpy(ie).to("cuda:0")
+        out = {}
+        for name, cls in (("items", ShardedRankingEvaluator), ("users", UserShardedRankingEvaluator)):
+            ev = cls((va[:, 0], va[:, 1]), (tr[:, 0], tr[:, 1]), [5, 10, 20], METRICS, U, I)
+            res = ev.evaluate(ue_d, ie_d)
+            assert all(v.is_cuda for v in res.values())      # the metrics stay on the device
+            out[name] = ({k: float(v) for k, v in res.items()}, ev.u_lo, ev.u_hi, ev.last_ids.cpu().numpy())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", BACKENDS)
+def test_sharded_evaluators_on_the_hip_kernels_equal_the_unsharded_one(backend, world):
+    from recommend_amd.evaluator import RankingEvaluator
+    results = _run(_eval_worker, world, backend)
+    U, I, ue, ie, tr, va = _eval_case()
+    ev = RankingEvaluator((va[:, 0], va[:, 1]), (tr[:, 0], tr[:, 1]), [5, 10, 20], METRICS, n_users=U)
+    ue_d, ie_d = torch.from_numpy(ue).to("cuda:0"), torch.from_numpy(ie).to("cuda:0")
+    want = {k: float(v) for k, v in ev.evaluate(ue_d, ie_d).items()}
+    _s, want_ids = ev.topk(ue_d, ie_d, 20)
+    want_ids = want_ids.cpu().numpy()
+    for _rank, out in results:
+        for form in ("items", "users"):
+            got, u_lo, u_hi, ids = out[form]
+            np.testing.assert_array_equal(ids, want_ids[u_lo:u_hi])
+            for k, v in want.items():
+                assert abs(got[k] - v) <= 1e-6, (form, k, got[k], v)
