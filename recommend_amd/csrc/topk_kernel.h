@@ -70,6 +70,32 @@ inline int choose_nsplit(int n_users, int n_items, int wgs_per_cu = 2) {
   return best;
 }
 
+// First position in [lo, hi) of the ascending list `items` whose entry is >= first.  A kernel's
+// prologue waits for this chain of dependent loads before its first tile, so it is a 4-ary search
+// (three independent probes per round: half the rounds of a bisection), and no search at all for a
+// slice that starts at the table's first item.
+__device__ __forceinline__ int32_t mask_lower_bound(const int32_t *__restrict__ items, int32_t lo, int32_t hi,
+                                                    int32_t first) {
+  if (first <= 0) return lo;
+  while (lo < hi) {
+    const int32_t n = hi - lo;
+    const int32_t p1 = lo + (n >> 2), p2 = lo + (n >> 1), p3 = lo + n - 1 - (n >> 2);
+    const int32_t v1 = items[p1], v2 = items[p2], v3 = items[p3];
+    if (v3 < first) {
+      lo = p3 + 1;
+    } else if (v2 < first) {
+      lo = p2 + 1;
+      hi = p3;
+    } else if (v1 < first) {
+      lo = p1 + 1;
+      hi = p2;
+    } else {
+      hi = p1;
+    }
+  }
+  return lo;
+}
+
 template <int KPAD>
 struct LaneList {
   float s[KPAD];
@@ -236,16 +262,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     if constexpr (FILTER) {
       if (heavy_thresh != nullptr && mend - mcur > heavy_thresh[0]) mcur = mend;   // left to the exact kernel (kHeavyUsers)
     }
-    int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
-    const int32_t first = t_lo * TI;
-    while (lo < hi) {
-      const int32_t mid = (lo + hi) >> 1;
-      if (mask_items[mid] < first)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    mcur = lo;
+    mcur = mask_lower_bound(mask_items, mcur, mend, t_lo * TI);   // skip entries in front of this slice
   }
   // The cursor holds the next TWO masked items: the entry consumed in a tile was loaded at
   // least one consumption earlier, so the loop below does not sit out a memory round trip

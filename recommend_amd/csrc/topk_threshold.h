@@ -126,16 +126,7 @@ struct StreamState {
       mcur = mask_ptr[user];
       mend = mask_ptr[user + 1];
       if (heavy_thresh != nullptr && mend - mcur > heavy_thresh[0]) mcur = mend;   // left to the exact kernel (kHeavyUsers)
-      int32_t lo = mcur, hi = mend;      // skip entries in front of this slice
-      const int32_t first = t_lo * TI;
-      while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (mask_items[mid] < first)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      mcur = lo;
+      mcur = mask_lower_bound(mask_items, mcur, mend, t_lo * TI);   // skip entries in front of this slice
     }
     // the cursor holds the next TWO masked items (see score_topk_kernel)
     next_m = mcur < mend ? mask_items[mcur] : INT32_MAX;
