@@ -312,8 +312,10 @@ struct KList {
   int32_t k[MAXK];
 };
 
-// NW: ranking places in units of 32 (1 for k <= 32; 4 for rankings of up to kMaxK places)
-template <int NW>
+// NW: words of relevance bits (1 for k <= 32; 4 for rankings of up to kMaxK places); NR: ranked ids a
+// lane holds in registers and compares every target item with (>= the largest k: 20 for the presets'
+// k <= 20, where 32 would spend a third of the kernel's compares on places that do not exist)
+template <int NW, int NR>
 __global__ __launch_bounds__(256) void rank_metrics_kernel(
     const int32_t *__restrict__ topk_ids, int32_t n_users, int32_t id_stride,
     const int32_t *__restrict__ tgt_ptr, const int32_t *__restrict__ tgt_items,
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
   if (u < n_users) {
     const int32_t tb = tgt_ptr[u], te = tgt_ptr[u + 1];
     const int32_t n_pos = te - tb;
-    constexpr int NR = 32 * NW;
+    static_assert(NR <= 32 * NW, "a relevance bit per ranked id");
     uint32_t rel[NW];  // bit j: j-th ranked item is a target item
 #pragma unroll
     for (int w = 0; w < NW; ++w) rel[w] = 0;
@@ -971,11 +973,14 @@ int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_str
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)rk::ceil_div(n_users, 256);
-  if (kmax <= 32)
-    rank_metrics_kernel<1><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
+  if (kmax <= 20)
+    rank_metrics_kernel<1, 20><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
+                                                  (double *)ws);
+  else if (kmax <= 32)
+    rank_metrics_kernel<1, 32><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
                                                 (double *)ws);
   else
-    rank_metrics_kernel<kMaxK / 32><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax,
+    rank_metrics_kernel<kMaxK / 32, kMaxK><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax,
                                                         discounts, (double *)ws);
   RK_CHECK_LAUNCH("rank_metrics_kernel");
   rank_metrics_final_kernel<<<1, 1024, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
