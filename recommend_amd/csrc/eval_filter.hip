@@ -39,16 +39,19 @@ __device__ __forceinline__ int scale_exponent(float maxabs) {
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ X, int64_t n_rows, int D,
                                                         float *__restrict__ norms,
                                                         float *__restrict__ row_maxabs,
-                                                        unsigned int *__restrict__ stats_part) {
+                                                        unsigned int *__restrict__ stats_part,
+                                                        __half *__restrict__ half_out, int32_t *__restrict__ row_exp) {
   const int per_row = D / 8;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / per_row;
   const int seg = (int)(t % per_row);
   float ss = 0.0f, mx = 0.0f;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (row < n_rows) {
     const float4 a = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg);
     const float4 b = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       ss = fmaf(v[j], v[j], ss);
@@ -65,6 +68,21 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
   if (row < n_rows && seg == 0) {
     if (norms) norms[row] = nrm;
     if (row_maxabs) row_maxabs[row] = mx;
+  }
+  // rows scaled by their OWN power of two (half_out given): every lane of the row's group holds the
+  // row's maximum now and the eight values it loaded, so the fp16 row leaves from here -- what
+  // to_half_rows_kernel does for a table that shares one exponent, which has to wait for the
+  // table's statistics
+  if (half_out != nullptr && row < n_rows) {
+    const int e = scale_exponent(mx);
+    if (row_exp && seg == 0) row_exp[row] = e;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = ldexpf(v[2 * j], -e), x1 = ldexpf(v[2 * j + 1], -e);
+      w[j] = (uint32_t)__half_as_ushort(__float2half_rn(x0)) | ((uint32_t)__half_as_ushort(__float2half_rn(x1)) << 16);
+    }
+    *reinterpret_cast<uint4 *>(half_out + row * D + 8 * seg) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   if (stats_part) {
     // one pair of atomics per wavefront; the maxima are taken on the bit patterns, so that a NaN
@@ -106,21 +124,18 @@ __global__ __launch_bounds__(rk::kStatSlots) void table_stats_kernel(const unsig
   }
 }
 
-// X[n_rows][D] fp32 -> fp16 rows of x * 2^-e, round to nearest even; e = the row's own exponent
-// (row_maxabs given; written to row_exp) or the table's (table_stats[1]).  One thread per 8
-// elements = 16 bytes of output.
+// X[n_rows][D] fp32 -> fp16 rows of x * 2^-e, round to nearest even, e = the table's exponent
+// (table_stats[1]); rows scaled by their own exponent are converted by row_stats_kernel.  One
+// thread per 8 elements = 16 bytes of output.
 __global__ __launch_bounds__(256) void to_half_rows_kernel(const float *__restrict__ X, int64_t n_rows, int D,
-                                                           const float *__restrict__ row_maxabs,
                                                            const float *__restrict__ table_stats,
-                                                           __half *__restrict__ out,
-                                                           int32_t *__restrict__ row_exp) {
+                                                           __half *__restrict__ out) {
   const int per_row = D / 8;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / per_row;
   const int seg = (int)(t % per_row);
   if (row >= n_rows) return;
-  const int e = scale_exponent(row_maxabs ? row_maxabs[row] : table_stats[1]);
-  if (row_exp && seg == 0) row_exp[row] = e;
+  const int e = scale_exponent(table_stats[1]);
   const float4 a = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg);
   const float4 b = *reinterpret_cast<const float4 *>(X + row * D + 8 * seg + 4);
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -534,15 +549,16 @@ int half_rows(const float *X, int64_t n_rows, int D, bool per_row_scale, void *o
               hipStream_t st) {
   if (n_rows == 0) return RK_OK;
   const unsigned grid = (unsigned)ceil_div(n_rows * (D / 8), 256);
-  row_stats_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, norms, per_row_scale ? row_maxabs : nullptr,
-                                         per_row_scale ? nullptr : stats_part);
-  RK_CHECK_LAUNCH("row_stats_kernel");
-  if (!per_row_scale) {
-    table_stats_kernel<<<1, kStatSlots, 0, st>>>(stats_part, table_stats);
-    RK_CHECK_LAUNCH("table_stats_kernel");
+  if (per_row_scale) {   // statistics and conversion in one pass over the rows
+    row_stats_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, norms, row_maxabs, nullptr, (__half *)out, row_exp);
+    RK_CHECK_LAUNCH("row_stats_kernel");
+    return RK_OK;
   }
-  to_half_rows_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, per_row_scale ? row_maxabs : nullptr, table_stats,
-                                            (__half *)out, per_row_scale ? row_exp : nullptr);
+  row_stats_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, norms, nullptr, stats_part, nullptr, nullptr);
+  RK_CHECK_LAUNCH("row_stats_kernel");
+  table_stats_kernel<<<1, kStatSlots, 0, st>>>(stats_part, table_stats);
+  RK_CHECK_LAUNCH("table_stats_kernel");
+  to_half_rows_kernel<<<grid, 256, 0, st>>>(X, n_rows, D, table_stats, (__half *)out);
   RK_CHECK_LAUNCH("to_half_rows_kernel");
   return RK_OK;
 }
