@@ -609,19 +609,26 @@ int threshold_candidates(int kc, int D, int32_t nsplit, hipStream_t st, const fl
   const int tgrid = (int)ceil_div(n_users, 4 * (64 / nsplit));   // 64 / nsplit users per wavefront
   if (D != 64 && D != 128) return fail(RK_ERR_UNSUPPORTED, "top-K filter: embedding width %d not built (64/128)", D);
   RK_CHECK_ARG(threshold_cand_bytes(n_users, nsplit) < ((size_t)1 << 32), "top-K filter: candidate places beyond 4 GiB");
-  if (D == 64)
+  // two or more slices: 32 strata per slice are enough (64 and more per user)
+  const bool half_strata = nsplit >= 2;
+  const int32_t n_strata = half_strata ? kStrata / 2 : kStrata;
+  if (D == 64 && half_strata)
+    strata_max_kernel<1, 3, true><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
+  else if (D == 64)
     strata_max_kernel<1, 3><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
+  else if (half_strata)
+    strata_max_kernel<2, 2, true><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
   else
     strata_max_kernel<2, 2><<<grid, 256, 0, st>>>(Uhalf, n_users, Ihalf, n_items, mask_ptr, mask_items, nsplit, heavy_thresh, strata);
   RK_CHECK_LAUNCH("strata_max_kernel");
   switch (kc) {
-    case 8: strata_threshold_kernel<8><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 12: strata_threshold_kernel<12><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 16: strata_threshold_kernel<16><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 20: strata_threshold_kernel<20><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 24: strata_threshold_kernel<24><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 28: strata_threshold_kernel<28><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
-    case 32: strata_threshold_kernel<32><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, thr); break;
+    case 8: strata_threshold_kernel<8><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 12: strata_threshold_kernel<12><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 16: strata_threshold_kernel<16><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 20: strata_threshold_kernel<20><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 24: strata_threshold_kernel<24><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 28: strata_threshold_kernel<28><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
+    case 32: strata_threshold_kernel<32><<<tgrid, 256, 0, st>>>(strata, n_users, nsplit, n_strata, thr); break;
     default: return fail(RK_ERR_UNSUPPORTED, "top-K filter: candidate list length %d not built", kc);
   }
   RK_CHECK_LAUNCH("strata_threshold_kernel");

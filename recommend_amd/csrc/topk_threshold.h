@@ -215,7 +215,14 @@ struct StreamState {
 // tile for user col in acc_a, for user 32 + col in acc_b), so no half swap is needed; the mask bits
 // of the two users a lane holds scores of are shuffled in from the lanes that own them.
 // Masked items count with the mask score, rows past the end of the table never (kNoItem).
-template <int DC, int NST>
+// HALF: 32 strata per slice (the position in the tile only) instead of 64 (position x parity of the
+// tile pair), for tables cut into two or more slices: a user still has 32 * nsplit >= 64 strata, and
+// the threshold kernel, which sorts them, has half as many to look at.  (With the 32 registers
+// that frees, a second accumulator set and the maxima of tile t folded between the MFMAs of tile
+// t + 1 at three wavefronts per SIMD was built as well -- 157 registers, the instruction stream
+// interleaved as intended -- and ran no faster: 19k x 7k 46 -> 42 us, 36k x 18k 124 -> 130, 24k x 63k
+// 219 -> 221.  What the probe shows for MFMAs and v_max alone does not carry over to this loop.)
+template <int DC, int NST, bool HALF = false>
 __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
     const float *__restrict__ Uemb, int32_t n_users, const float *__restrict__ Iemb, int32_t n_items,
     const int32_t *__restrict__ mask_ptr, const int32_t *__restrict__ mask_items, int32_t nsplit,
@@ -234,9 +241,10 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
   StreamState<DC> st;
   st.init(Uemb, n_users, ubase, lane, wave, mask_ptr, mask_items, heavy_thresh, t_lo);
 
-  float sa[2][16], sb[2][16];
+  constexpr int NG = HALF ? 1 : 2;
+  float sa[NG][16], sb[NG][16];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[g][r] = sb[g][r] = -INFINITY;
 
@@ -296,27 +304,27 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        RK_VMAX(sa[j >> 1][r], acc_a[r]);
-        RK_VMAX(sb[j >> 1][r], acc_b[r]);
+        RK_VMAX(sa[HALF ? 0 : j >> 1][r], acc_a[r]);
+        RK_VMAX(sb[HALF ? 0 : j >> 1][r], acc_b[r]);
       }
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
 
-  // user col: values [32*half, 32*half + 32) of its kStrata; user 32 + col likewise
+  // user col: values [16*NG*half, 16*NG*(half + 1)) of its kStrata places; user 32 + col likewise
   if (ubase + col < n_users) {
-    float *dst = strata + ((int64_t)(ubase + col) * nsplit + split) * kStrata + 32 * half;
+    float *dst = strata + ((int64_t)(ubase + col) * nsplit + split) * kStrata + 16 * NG * half;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4 *>(dst + 16 * g + 4 * q) =
             make_float4(sa[g][4 * q], sa[g][4 * q + 1], sa[g][4 * q + 2], sa[g][4 * q + 3]);
   }
   if (ubase + 32 + col < n_users) {
-    float *dst = strata + ((int64_t)(ubase + 32 + col) * nsplit + split) * kStrata + 32 * half;
+    float *dst = strata + ((int64_t)(ubase + 32 + col) * nsplit + split) * kStrata + 16 * NG * half;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4 *>(dst + 16 * g + 4 * q) =
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void strata_max_kernel(
 // lists in LDS took 57 us, a chain of dependent LDS reads.)
 template <int KC>
 __global__ __launch_bounds__(256) void strata_threshold_kernel(const float *__restrict__ strata, int32_t n_users,
-                                                               int32_t nsplit, float *__restrict__ thr) {
+                                                               int32_t nsplit, int32_t n_strata, float *__restrict__ thr) {
   __shared__ float lists[256][KC + 1];     // (odd row length: the lanes' accesses spread over the banks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int upw = 64 / nsplit;             // users per wavefront (nsplit <= 16)
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256) void strata_threshold_kernel(const float *__re
 #pragma unroll
   for (int j = 0; j < KC; ++j) s[j] = -INFINITY;
   const float *p = strata + ((int64_t)(ok ? user : 0) * nsplit + (ok ? sl : 0)) * kStrata;
-  for (int32_t i = 0; i < kStrata; i += 4) {
+  for (int32_t i = 0; i < n_strata; i += 4) {   // (n_strata of the slice's kStrata places are in use)
     const float4 v4 = *reinterpret_cast<const float4 *>(p + i);
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
