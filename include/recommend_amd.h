@@ -432,8 +432,8 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * by fp16 scores (both tables copied to fp16, one fp16 MFMA per 16 k), picks candidates per user
  * -- the K+8 best by sorted lists in one pass over the scores (long item tables that one slice
  * per user tile covers), or every item at or above a per-user threshold, the (K+8)-th largest of
- * the maxima of 64 disjoint strata of the items, in two passes (short tables, item shards, small
- * user blocks); RK_FILTER_FORM=lists|threshold in the environment, read at every call, forces a
+ * the maxima of disjoint strata of the items (64 per user, or 32 per item slice when a table is cut
+ * into several), in two passes (short tables, item shards, small user blocks); RK_FILTER_FORM=lists|threshold in the environment, read at every call, forces a
  * form --, re-scores the candidates with the exact chain, and runs the exact kernel only for
  * users whose result that procedure cannot certify (the fp16 bound on what lies outside the
  * candidates within the fp16 error of the K-th exact score: ties at the K-th place, non-finite
