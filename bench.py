@@ -51,6 +51,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 MFMA_F32_PEAK_TFS = 157.3    # MI355X fp32 matrix peak
 MFMA_F16_PEAK_TFS = 2500.0   # MI355X dense fp16 / bf16 matrix peak
 BATCH = {"baby": 2048, "clothing": 1024, "sports": 256, "elec": 256}   # reference config.py presets
+EMB_DIM = {"baby": 64, "clothing": 128, "sports": 64, "elec": 64}       # config.py:188,201,212,223
+LR = {"baby": 1e-3, "clothing": 5e-4, "sports": 1e-3, "elec": 1e-3}    # config.py:64,203,214,225
 
 
 def kernel_source_digest():
@@ -158,13 +160,61 @@ def cpu_baseline_train(model, feats, coo, batch, U, I, reps_spmm=5):
     padded = [torch.cat([torch.zeros(U, f.shape[1]), f]) for f in feats.values()]
     embs = model.embs.detach().cpu().clone().requires_grad_(True)
     alphas = model.alphas.detach().cpu().clone().requires_grad_(True)
-    t0 = time.perf_counter()
-    ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"], embs, model.ks, alphas,
-                                  model.config.model.layer_num, U)
-    loss = loss_oracle.trainer_loss({"user_embeddings": ue, "item_embeddings": ie},
-                                    {k: batch[k].cpu() for k in ("user_ids", "item_ids", "neg_items")})
-    loss.backward()
-    return ms_hop, 1e3 * (time.perf_counter() - t0)
+    for _ in range(2):       # the first step pays allocator and thread-pool start-up: the second is reported
+        t0 = time.perf_counter()
+        ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"], embs, model.ks, alphas,
+                                      model.config.model.layer_num, U)
+        loss = loss_oracle.trainer_loss({"user_embeddings": ue, "item_embeddings": ie},
+                                        {k: batch[k].cpu() for k in ("user_ids", "item_ids", "neg_items")})
+        loss.backward()
+        ms_step = 1e3 * (time.perf_counter() - t0)
+    return ms_hop, ms_step
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, backend):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself (one
+    child process per GPU, the same command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), hands rank 0's JSON line through and exits with the worst exit code.  It runs
+    before anything here has touched a GPU (counting devices does not), so no process that holds
+    the GPU ever starts another program in its place."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"[bench] --gpus {n} on the nccl (RCCL) backend needs {n} visible GPUs, this machine shows {have}: "
+              "RCCL does not run two ranks on one device.  Nothing was measured.  (BENCH_BACKEND=gloo rehearses "
+              "the N-rank code with the ranks sharing the visible GPUs and the collectives going through the host.)",
+              file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               BENCH_BACKEND=backend)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    limit = float(os.environ.get("BENCH_JOB_LIMIT_S", "1500"))
+    t0, worst = time.time(), 0
+    try:
+        out, _ = procs[0].communicate(timeout=limit)
+        sys.stdout.write(out.decode())
+        sys.stdout.flush()
+        for p in procs:
+            worst = max(worst, abs(p.wait(timeout=max(1.0, limit - (time.time() - t0)))))
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the {n}-rank job did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
+        worst = 124
+    finally:
+        for p in procs:           # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.kill()
+    return worst
 
 
 def main():
@@ -173,7 +223,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="elec", choices=list(synth.SHAPES))
-    ap.add_argument("--emb-dim", type=int, default=64)
+    ap.add_argument("--emb-dim", type=int, default=None, help="default: the reference preset of the shape")
     ap.add_argument("--epoch-steps", type=int, default=-1,
                     help="training steps to time for the epoch figure (-1: the whole epoch, 0: skip)")
     ap.add_argument("--cpu-users", type=int, default=8192, help="users in the CPU baseline sample (0: skip)")
@@ -185,9 +235,15 @@ def main():
     args = ap.parse_args()
     if args.pmc_pass:
         args.steps, args.warmup, args.epoch_steps, args.cpu_users, args.spmm_reps = 2, 0, 0, 0, 5
+    if args.emb_dim is None:
+        args.emb_dim = EMB_DIM[args.shape]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, os.environ.get("BENCH_BACKEND", "nccl")))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and rank == 0:
+        log(f"[bench] the launcher started {world} ranks, --gpus says {args.gpus}: measuring {world}")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)   # BENCH_BACKEND=gloo rehearsals share one GPU
     torch.cuda.set_device(local)
@@ -200,7 +256,11 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
+            # rehearsal of the N-rank code with the ranks sharing the visible GPUs: gloo moves host memory
             dist.init_process_group(backend)
+            from recommend_amd import dist as rk_dist
+            from tools.host_staged_transport import HostStagedTransport
+            rk_dist.set_transport(HostStagedTransport())
 
     U, I, E = synth.SHAPES[args.shape]
     D = args.emb_dim
@@ -314,13 +374,13 @@ def main():
     ms_spmm_t = event_ms(lambda: ops.spmm_raw(gc.graph.bwd, h, out=buf), args.spmm_reps)
 
     # ---------------------------------------------------------------- one training epoch
-    epoch = None
+    epoch = trained = None
     if args.epoch_steps != 0 and not dist_on:
         p_ptr, p_items = build_user_csr(data.users, data.items, U)
         sampler = NegativeSampler(p_ptr, p_items, I, seed=42)
         dp, di = sampler.device_csr(dev)
         loader = TrainBatchLoader(tu, ti, tr, BATCH[args.shape], sampler, device=dev, resolve_on_host=False)
-        opt = FusedClipAdam(model.parameters(), lr=1e-3)
+        opt = FusedClipAdam(model.parameters(), lr=LR[args.shape])
         model.train()
         n_steps = len(loader) if args.epoch_steps < 0 else min(args.epoch_steps, len(loader))
         it = iter(loader)
@@ -351,6 +411,30 @@ def main():
                  "composition": "steps_per_epoch * ms_per_train_step + one eval forward + one eval step",
                  "whole_epoch_timed": n_steps == full}
         log(f"[bench] epoch: {n_steps - 3} steps timed, {ms_train:.3f} ms/step")
+        # the evaluation step again, on the embeddings an evaluator sees after training: the filter's
+        # speed depends on how many users it certifies, which depends on the embeddings
+        model.eval()
+        with torch.no_grad():
+            out_t = model({})
+        ue_t, ie_t = out_t["user_embeddings"].contiguous(), out_t["item_embeddings"].contiguous()
+        model.train()
+        for _ in range(max(args.warmup, 1)):
+            res_t = ev.evaluate(ue_t, ie_t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res_t = ev.evaluate(ue_t, ie_t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        trained = {"value_trained": round(U * args.steps / dt, 1), "ms_per_step_trained": round(1e3 * dt / args.steps, 4),
+                   "train_steps_before": n_steps, "recall@20_trained": round(float(res_t["recall@20"]), 6),
+                   "open_users_trained": ops.score_topk_open_users(ue_t, ie_t, 20, *ev.mask_csr(dev)),
+                   "open_users": ops.score_topk_open_users(ue, ie, 20, *ev.mask_csr(dev)),
+                   "item_norm_max_over_median": round(float(ie_t.norm(dim=1).max() / ie_t.norm(dim=1).median()), 3),
+                   "note": "the same step on the model's embeddings after the timed training steps; open_users = users "
+                           "the candidate filter left to the exact kernel (of them up to 512 by rule: the longest training lists)"}
+        log(f"[bench] trained embeddings: {trained['ms_per_step_trained']:.3f} ms/step, open users "
+            f"{trained['open_users_trained']} (at initialisation {trained['open_users']})")
 
     # ---------------------------------------------------------------- CPU baseline
     cpu = None
@@ -370,7 +454,7 @@ def main():
             cpu["spmm_hop_ms"] = round(ms_hop, 3)
             cpu["train_step_ms"] = round(ms_step, 1)
             cpu["train_sample"] = "one torch.sparse.mm hop (mean of 5) and one forward + BPR loss + backward of the " \
-                                  "oracle's MMFCN at the same shape, no warm-up step"
+                                  "oracle's MMFCN at the same shape (the second of two steps)"
 
     # N > 1: the same evaluation with the ITEMS cut over the ranks instead of the users (per-GPU top-K over
     # its item shard, exchange of the per-user lists, merge; for item tables too large for one GPU): timed
@@ -378,13 +462,13 @@ def main():
     user_sharded = None
     sharded_hop = sharded_train = None
 
-    def emit():
+    def emit(error=None):
         if rank == 0:
             line = {
                 "metric": "MMFCN epoch time + full-rank top-20 eval users/sec (Elec shape), SpMM HBM GB/s",
                 "value": round(users_per_s, 1), "unit": "users/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-                "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+                "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32 (results; candidates by fp16 MFMA, certified against the fp32 chain)",
                 "data": "synthetic",
                 "config": {"workload": f"{args.shape} shape: {U} users x {I} items, {len(tu)} train interactions, "
@@ -392,10 +476,14 @@ def main():
                            "parallelism": "single GPU" if world == 1 else f"users in {world} blocks (one per GPU) against the whole item table, all-reduce of the metric sums"},
                 "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
                 "spmm_transpose_ms": round(ms_spmm_t, 5),
-                "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "cpu_baseline": cpu,
+                "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "trained": trained, "cpu_baseline": cpu,
                 "recall@20": round(float(res["recall@20"]), 6),
                 "kernel_source_digest": kernel_source_digest(),
             }
+            if trained is not None:
+                line["value_trained"] = trained["value_trained"]
+            if error is not None:
+                line["error"] = error
             if args.pmc_pass:
                 line["pmc_pass_calls"] = {"score_topk_call": topk_calls}
             if dist_on:
@@ -405,8 +493,8 @@ def main():
             print(json.dumps(line), flush=True)
 
     # The legs below are reported beside the headline and run after it.  They contain collectives; should
-    # one of them never return (they have run over gloo only), every rank gives up after a while and rank 0
-    # prints the line with what has been measured.
+    # one of them never return, every rank gives up after a while: rank 0 prints the line with what has
+    # been measured and a top-level "error", and the process exits non-zero.
     watchdog = None
     if dist_on:
         import threading
@@ -417,8 +505,9 @@ def main():
             user_sharded = user_sharded or note
             sharded_hop = sharded_hop or note
             sharded_train = sharded_train or note
-            emit()
-            os._exit(0)
+            emit(error="a leg of the N > 1 run (item_sharded_eval / row_sharded_hop / row_sharded_train_step) did not "
+                       "finish within its time limit; the headline value was measured before it")
+            os._exit(3)
         watchdog = threading.Timer(float(os.environ.get("BENCH_LEG_LIMIT_S", "420")), give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -484,16 +573,28 @@ def main():
             smodel.build_graph((tu[idx], ti[idx], tr[idx]), index=idx, n_total=len(tu))
             smodel.creat_feature_weight()
             smodel.train()
-            sopt = torch.optim.Adam(smodel.parameters(), lr=1e-3)
+            sopt = FusedClipAdam(smodel.parameters(), lr=LR[args.shape])
             sstep = ShardedTrainStep(smodel, sopt, gather_dot_bpr_loss, max_grad_norm=1.0)
-            Bg = BATCH[args.shape] * world          # weak scaling: the per-GPU batch is the preset's
+            Bg = BATCH[args.shape] * world          # the per-GPU batch is the preset's
             gen = np.random.default_rng(7)
             def global_batch():
                 sel = gen.integers(0, len(tu), Bg)
                 return {"user_ids": torch.from_numpy(tu[sel]).to(dev), "item_ids": torch.from_numpy(ti[sel]).to(dev),
                         "neg_items": torch.from_numpy(gen.integers(0, I, (Bg, 1))).to(dev)}
             batches = [global_batch() for _ in range(8)]
-            for b in batches[:3]:
+            # the step, collectives included, as one captured HIP graph per rank (RCCL only; the gloo
+            # rehearsal runs it eagerly); BENCH_SHARDED_EAGER=1 times the eager form on RCCL as well
+            captured = backend == "nccl" and os.environ.get("BENCH_SHARDED_EAGER") != "1"
+            capture_error = None
+            try:
+                sstep = sstep.graphed(batches[0], warmup_steps=3, capture=captured)
+            except Exception as e:      # the recording failed (on every rank alike): time the eager step instead
+                if not captured:
+                    raise
+                capture_error, captured = repr(e), False
+                torch.cuda.synchronize()
+                sstep = ShardedTrainStep(smodel, sopt, gather_dot_bpr_loss, max_grad_norm=1.0)
+            for b in batches[:2]:
                 sstep(b)
             torch.cuda.synchronize()
             dist.barrier()
@@ -507,8 +608,11 @@ def main():
             all_reduce_tensor(t, dist.ReduceOp.MAX)
             sharded_train = {"ms_per_train_step": round(float(t), 4), "global_batch": Bg, "steps_timed": n_timed,
                              "last_loss": round(float(last), 6),
+                             "captured_graph": bool(captured), "capture_error": capture_error,
                              "layout": f"rows of the graph and of every node matrix over {world} ranks, batch split; "
-                                       "eager launches (no captured graph: the step contains collectives)"}
+                                       "clip + Adam by the library's kernel pair; "
+                                       + ("one captured HIP graph per rank, RCCL collectives inside" if captured
+                                          else "eager launches")}
         except Exception as e:
             sharded_train = {"error": repr(e)}
     if watchdog is not None:

@@ -290,6 +290,21 @@ int rk_adam_clip_step_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors,
                           int64_t *step, const float *lr, float beta1, float beta2,
                           float eps, float weight_decay, float max_norm,
                           float *norm_out, void *ws, size_t ws_bytes, void *stream);
+/* The same step for parameters spread over several GPUs (the reference trains in one process:
+ * train/graph_trainer.py:133-165 has no counterpart of the exchange).  tensors_host[0 ..
+ * n_replicated) hold gradients that are whole and equal on every rank, the tensors behind them
+ * are row shards.  rk_adam_sqnorm_f32 writes every chunk's sum of squares into ws, increments
+ * `step` and leaves the sum over the SHARDS' chunks in shard_sq_out[0] (device; 0 without
+ * shards).  The caller sums that float over the ranks (one all-reduce) and passes it to
+ * rk_adam_update_f32 as shard_sq (may be NULL when n_replicated == n_tensors), which clips by the
+ * norm over replicated + all shards and updates -- the same arithmetic as rk_adam_clip_step_f32,
+ * which is these two calls with every tensor replicated.  Same ws for both calls. */
+int rk_adam_sqnorm_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors, int32_t n_replicated,
+                       int64_t *step, float *shard_sq_out, void *ws, size_t ws_bytes, void *stream);
+int rk_adam_update_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors, int32_t n_replicated,
+                       const int64_t *step, const float *lr, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, const float *shard_sq, float *norm_out,
+                       const void *ws, size_t ws_bytes, void *stream);
 
 /* ---- N: negative sampling (host RNG, bit-exact) ------------------------- */
 /* Replaces GraphDataLoader._generate_negative_samples,

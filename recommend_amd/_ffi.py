@@ -103,6 +103,9 @@ SIGNATURES = {
     "rk_adam_ws_bytes": (c_size_t, [P, c_int32]),
     "rk_adam_clip_step_f32": (c_int32, [P, c_int32, P, P, c_float, c_float, c_float, c_float, c_float, P, P,
                                         c_size_t, P]),
+    "rk_adam_sqnorm_f32": (c_int32, [P, c_int32, c_int32, P, P, P, c_size_t, P]),
+    "rk_adam_update_f32": (c_int32, [P, c_int32, c_int32, P, P, c_float, c_float, c_float, c_float, c_float, P, P, P,
+                                     c_size_t, P]),
     "rk_mt_seed_host": (c_int32, [P, c_uint64]),
     "rk_neg_sample_host": (c_int32, [P, P, c_int64, c_int32, P, P, c_int32, P, P]),
     "rk_neg_order_host": (c_int32, [P, c_int32, c_int32, P]),

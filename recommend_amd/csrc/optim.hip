@@ -10,6 +10,12 @@
 // the same order and hence the same bits everywhere), derives the clip factor and applies Adam's
 // update to its chunk.  No float atomics; the step count lives in device memory so that a launch
 // replayed from a captured HIP graph advances it.
+//
+// Several GPUs (rk_adam_sqnorm_f32 + rk_adam_update_f32): the first n_replicated tensors hold
+// whole gradients that are equal on every rank; the tensors behind them are row shards, whose
+// squared norms are partial.  The first call leaves the sum over the shards' chunks in one device
+// float; the caller all-reduces that float over the ranks and hands it to the second call, whose
+// workgroups add it to the replicated chunks' sum: every rank derives the same clip factor.
 #include <algorithm>
 
 #include "common.h"
@@ -62,8 +68,24 @@ __global__ __launch_bounds__(256) void adam_sqnorm_kernel(AdamArgs args, float *
   }
 }
 
+// sum of partial[first .. first + count) in a fixed order: the squared norm of the row shards on this rank
+__global__ __launch_bounds__(256) void adam_shard_sum_kernel(const float *__restrict__ partial, int32_t first,
+                                                             int32_t count, float *__restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  for (int32_t c = threadIdx.x; c < count; c += 256) s += partial[first + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, rk::kWave);
+  if (threadIdx.x % rk::kWave == 0) red[threadIdx.x / rk::kWave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// n_chunks: the chunks whose partial sums every workgroup adds itself (all of them on one GPU, those of
+// the replicated tensors otherwise); shard_sq (may be NULL): the shards' squared norm summed over ranks
 __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs args, int32_t n_chunks,
                                                           const float *__restrict__ partial,
+                                                          const float *__restrict__ shard_sq,
                                                           const int64_t *__restrict__ step, const float *__restrict__ lr_dev,
                                                           float beta1, float beta2, float eps, float weight_decay,
                                                           float max_norm, float *__restrict__ norm_out) {
@@ -75,7 +97,9 @@ __global__ __launch_bounds__(256) void adam_update_kernel(AdamArgs args, int32_t
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, rk::kWave);
   if (threadIdx.x % rk::kWave == 0) red[threadIdx.x / rk::kWave] = s;
   __syncthreads();
-  const float total = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  float sq = (red[0] + red[1]) + (red[2] + red[3]);
+  if (shard_sq) sq += shard_sq[0];
+  const float total = sqrtf(sq);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = total;
   // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
   const float coef = max_norm > 0.0f ? fminf(max_norm / (total + 1e-6f), 1.0f) : 1.0f;
@@ -111,48 +135,101 @@ size_t rk_adam_ws_bytes(const rk_adam_tensor *tensors_host, int32_t n_tensors) {
   return (size_t)(chunks + 1) * sizeof(float);
 }
 
+namespace {
+
+int check_tensors(const rk_adam_tensor *tensors_host, int32_t n_tensors, int32_t n_replicated, const void *ws,
+                  size_t ws_bytes, int64_t *total_chunks, int64_t *replicated_chunks) {
+  RK_CHECK_ARG(tensors_host && ws, "null pointer");
+  RK_CHECK_ARG(n_replicated >= 0 && n_replicated <= n_tensors, "n_replicated outside [0, n_tensors]");
+  RK_CHECK_ARG(ws_bytes >= rk_adam_ws_bytes(tensors_host, n_tensors), "workspace too small");
+  int64_t total = 0, rep = 0;
+  for (int32_t i = 0; i < n_tensors; ++i) {
+    const rk_adam_tensor &t = tensors_host[i];
+    RK_CHECK_ARG(t.n > 0 && t.param && t.grad && t.exp_avg && t.exp_avg_sq, "tensor %d: null pointer or empty", i);
+    total += rk::ceil_div(t.n, kChunk);
+    if (i < n_replicated) rep = total;
+  }
+  RK_CHECK_ARG(total < INT32_MAX, "too many elements");
+  *total_chunks = total;
+  *replicated_chunks = rep;
+  return RK_OK;
+}
+
+// pass 0: every chunk's sum of squares (and the step bump); pass 1: the updates
+int launch_pass(int pass, const rk_adam_tensor *tensors_host, int32_t n_tensors, int64_t *step, const float *lr,
+                float beta1, float beta2, float eps, float weight_decay, float max_norm, int32_t sum_chunks,
+                const float *shard_sq, float *norm_out, float *partial, hipStream_t st) {
+  int32_t chunk_base = 0;
+  for (int32_t g0 = 0; g0 < n_tensors; g0 += kMaxTensors) {
+    AdamArgs args;
+    args.n = std::min(kMaxTensors, n_tensors - g0);
+    int32_t c = 0;
+    for (int i = 0; i < args.n; ++i) {
+      args.t[i] = tensors_host[g0 + i];
+      args.chunk_start[i] = c;
+      c += (int32_t)rk::ceil_div(args.t[i].n, kChunk);
+    }
+    args.chunk_start[args.n] = c;
+    if (pass == 0) {
+      adam_sqnorm_kernel<<<c, 256, 0, st>>>(args, partial + chunk_base, step, g0 == 0);
+      RK_CHECK_LAUNCH("adam_sqnorm_kernel");
+    } else {
+      adam_update_kernel<<<c, 256, 0, st>>>(args, sum_chunks, partial, shard_sq, step, lr, beta1, beta2, eps,
+                                            weight_decay, max_norm, norm_out);
+      RK_CHECK_LAUNCH("adam_update_kernel");
+    }
+    chunk_base += c;
+  }
+  return RK_OK;
+}
+
+}  // namespace
+
+int rk_adam_sqnorm_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors, int32_t n_replicated, int64_t *step,
+                       float *shard_sq_out, void *ws, size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(n_tensors >= 0, "negative tensor count");
+  if (n_tensors == 0) return RK_OK;
+  RK_CHECK_ARG(step && shard_sq_out, "null pointer");
+  int64_t total = 0, rep = 0;
+  if (int rc = check_tensors(tensors_host, n_tensors, n_replicated, ws, ws_bytes, &total, &rep)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = launch_pass(0, tensors_host, n_tensors, step, nullptr, 0, 0, 0, 0, 0, 0, nullptr, nullptr, (float *)ws, st))
+    return rc;
+  adam_shard_sum_kernel<<<1, 256, 0, st>>>((const float *)ws, (int32_t)rep, (int32_t)(total - rep), shard_sq_out);
+  RK_CHECK_LAUNCH("adam_shard_sum_kernel");
+  return RK_OK;
+}
+
+int rk_adam_update_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors, int32_t n_replicated, const int64_t *step,
+                       const float *lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                       const float *shard_sq, float *norm_out, const void *ws, size_t ws_bytes, void *stream) {
+  RK_CHECK_ARG(n_tensors >= 0, "negative tensor count");
+  if (n_tensors == 0) return RK_OK;
+  RK_CHECK_ARG(step && lr, "null pointer");
+  RK_CHECK_ARG(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "bad Adam constants");
+  int64_t total = 0, rep = 0;
+  if (int rc = check_tensors(tensors_host, n_tensors, n_replicated, ws, ws_bytes, &total, &rep)) return rc;
+  RK_CHECK_ARG(shard_sq || rep == total, "row-sharded tensors need the all-reduced squared norm of the shards");
+  return launch_pass(1, tensors_host, n_tensors, const_cast<int64_t *>(step), lr, beta1, beta2, eps, weight_decay,
+                     max_norm, (int32_t)rep, rep == total ? nullptr : shard_sq, norm_out,
+                     const_cast<float *>((const float *)ws), (hipStream_t)stream);
+}
+
 int rk_adam_clip_step_f32(const rk_adam_tensor *tensors_host, int32_t n_tensors, int64_t *step, const float *lr,
                           float beta1, float beta2, float eps, float weight_decay, float max_norm, float *norm_out,
                           void *ws, size_t ws_bytes, void *stream) {
   RK_CHECK_ARG(n_tensors >= 0, "negative tensor count");
   if (n_tensors == 0) return RK_OK;
-  RK_CHECK_ARG(tensors_host && step && lr && ws, "null pointer");
+  RK_CHECK_ARG(step && lr, "null pointer");
   RK_CHECK_ARG(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "bad Adam constants");
-  RK_CHECK_ARG(ws_bytes >= rk_adam_ws_bytes(tensors_host, n_tensors), "workspace too small");
-  for (int32_t i = 0; i < n_tensors; ++i) {
-    const rk_adam_tensor &t = tensors_host[i];
-    RK_CHECK_ARG(t.n > 0 && t.param && t.grad && t.exp_avg && t.exp_avg_sq, "tensor %d: null pointer or empty", i);
-  }
+  int64_t total = 0, rep = 0;
+  if (int rc = check_tensors(tensors_host, n_tensors, n_tensors, ws, ws_bytes, &total, &rep)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  float *partial = (float *)ws;
-  // launch groups of up to kMaxTensors tensors; all partial sums first, then all updates
-  int64_t total_chunks = 0;
-  for (int32_t i = 0; i < n_tensors; ++i) total_chunks += rk::ceil_div(tensors_host[i].n, kChunk);
-  RK_CHECK_ARG(total_chunks < INT32_MAX, "too many elements");
-  for (int pass = 0; pass < 2; ++pass) {
-    int32_t chunk_base = 0;
-    for (int32_t g0 = 0; g0 < n_tensors; g0 += kMaxTensors) {
-      AdamArgs args;
-      args.n = std::min(kMaxTensors, n_tensors - g0);
-      int32_t c = 0;
-      for (int i = 0; i < args.n; ++i) {
-        args.t[i] = tensors_host[g0 + i];
-        args.chunk_start[i] = c;
-        c += (int32_t)rk::ceil_div(args.t[i].n, kChunk);
-      }
-      args.chunk_start[args.n] = c;
-      if (pass == 0) {
-        adam_sqnorm_kernel<<<c, 256, 0, st>>>(args, partial + chunk_base, step, g0 == 0);
-        RK_CHECK_LAUNCH("adam_sqnorm_kernel");
-      } else {
-        adam_update_kernel<<<c, 256, 0, st>>>(args, (int32_t)total_chunks, partial, step, lr, beta1, beta2, eps,
-                                              weight_decay, max_norm, norm_out);
-        RK_CHECK_LAUNCH("adam_update_kernel");
-      }
-      chunk_base += c;
-    }
-  }
-  return RK_OK;
+  // all partial sums first, then all updates
+  if (int rc = launch_pass(0, tensors_host, n_tensors, step, nullptr, 0, 0, 0, 0, 0, 0, nullptr, nullptr, (float *)ws, st))
+    return rc;
+  return launch_pass(1, tensors_host, n_tensors, step, lr, beta1, beta2, eps, weight_decay, max_norm, (int32_t)total,
+                     nullptr, norm_out, (float *)ws, st);
 }
 
 }  // extern "C"

@@ -28,53 +28,69 @@ import torch.distributed as dist
 from .evaluator import METRIC_ORDER, pairs_to_csr, restrict_csr, target_to_csr, _pad64
 
 
-def _via_host(group):
-    """gloo rehearsals (several ranks sharing one GPU) exchange through host memory;
-    with nccl (= RCCL) the device tensors go over xGMI directly."""
-    return dist.get_backend(group) == "gloo"
+class DirectTransport:
+    """How tensors reach the collectives: as they are.  On the GPU box the process group is "nccl"
+    (= RCCL) and device tensors go over xGMI; CPU tensors with a gloo group work the same way."""
+
+    @staticmethod
+    def collective_device(device):
+        """Where index tensors exchanged while a plan is built should live."""
+        return torch.device(device)
+
+    @staticmethod
+    def all_gather(out_list, t, group):
+        dist.all_gather(out_list, t, group=group)
+
+    @staticmethod
+    def all_gather_into(out, t, group):
+        dist.all_gather_into_tensor(out, t, group=group)
+
+    @staticmethod
+    def reduce_scatter(out, full, group):
+        dist.reduce_scatter_tensor(out, full, group=group)
+
+    @staticmethod
+    def all_reduce(t, op, group):
+        dist.all_reduce(t, op=op, group=group)
+
+    @staticmethod
+    def all_to_all(out, src, out_splits, in_splits, group):
+        dist.all_to_all_single(out, src, out_splits, in_splits, group=group)
+
+
+_transport = DirectTransport()
+
+
+def set_transport(transport):
+    """Replace the object the collectives below go through (same methods as DirectTransport).
+    Rehearsals that run several ranks on ONE GPU cannot use RCCL and hand in a transport that
+    stages device tensors through host memory for a gloo group; production never calls this."""
+    global _transport
+    old, _transport = _transport, (transport or DirectTransport())
+    return old
 
 
 def all_gather_tensor(t, world, group=None):
-    if _via_host(group) and t.is_cuda:
-        c = t.cpu()
-        out = [torch.empty_like(c) for _ in range(world)]
-        dist.all_gather(out, c, group=group)
-        return [o.to(t.device) for o in out]
     out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t.contiguous(), group=group)
+    _transport.all_gather(out, t.contiguous(), group)
     return out
 
 
 def all_gather_rows_into(buf, x_local, group=None):
     """buf[r * n : (r + 1) * n] = rank r's x_local ([n, D], the same n on every rank); buf is the
     caller's preallocated [world * n, D] tensor (no list of pieces, no concatenation)."""
-    if _via_host(group) and x_local.is_cuda:
-        host = torch.empty(buf.shape, dtype=buf.dtype)
-        dist.all_gather_into_tensor(host, x_local.detach().cpu().contiguous(), group=group)
-        buf.copy_(host)
-        return buf
-    dist.all_gather_into_tensor(buf, x_local.detach().contiguous(), group=group)
+    _transport.all_gather_into(buf, x_local.detach().contiguous(), group)
     return buf
 
 
 def reduce_scatter_rows(out_local, full, group=None):
     """out_local ([n, D]) = sum over ranks of their full[rank * n : (rank + 1) * n]."""
-    if _via_host(group) and full.is_cuda:
-        host = torch.empty(out_local.shape, dtype=out_local.dtype)
-        dist.reduce_scatter_tensor(host, full.detach().cpu().contiguous(), group=group)
-        out_local.copy_(host)
-        return out_local
-    dist.reduce_scatter_tensor(out_local, full.detach().contiguous(), group=group)
+    _transport.reduce_scatter(out_local, full.detach().contiguous(), group)
     return out_local
 
 
 def all_reduce_tensor(t, op=dist.ReduceOp.SUM, group=None):
-    if _via_host(group) and t.is_cuda:
-        c = t.cpu()
-        dist.all_reduce(c, op=op, group=group)
-        t.copy_(c)
-        return t
-    dist.all_reduce(t, op=op, group=group)
+    _transport.all_reduce(t, op, group)
     return t
 
 
@@ -84,12 +100,9 @@ def exchange_user_slices(packed, n_users, rank, world, group=None):
     bounds = [user_range(n_users, r, world) for r in range(world)]
     in_split = [hi - lo for lo, hi in bounds]
     mine = in_split[rank]
-    via_host = _via_host(group) and packed.is_cuda
-    src = packed.cpu() if via_host else packed.contiguous()
+    src = packed.contiguous()
     out = torch.empty((world * mine, packed.shape[1]), dtype=src.dtype, device=src.device)
-    dist.all_to_all_single(out, src, [mine] * world, in_split, group=group)
-    if via_host:
-        out = out.to(packed.device)
+    _transport.all_to_all(out, src, [mine] * world, in_split, group)
     return out.view(world, mine, packed.shape[1])
 
 
@@ -285,11 +298,6 @@ class HipRowBlock:
         self.mat.n_cols = int(n_cols)
 
 
-def _collective_device(group, device):
-    """Where the tensors of a collective live: on the GPU for nccl, on the host for gloo."""
-    return torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device(device)
-
-
 class HaloPlan:
     """Which rows of the other ranks' blocks the columns of one row block reference, and the
     exchange that fetches exactly those: rank r sends rank q the rows of its block that q's edges
@@ -312,15 +320,15 @@ class HaloPlan:
         self.need = np.unique(outside)                      # ascending global ids = grouped by owner rank
         owner = self.need // block
         recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
-        cdev = _collective_device(group, device)
+        cdev = _transport.collective_device(device)
         # every owner learns how many, then which, of its rows this rank reads
         rc = torch.from_numpy(recv_counts).to(cdev)
         sc = torch.empty_like(rc)
-        dist.all_to_all_single(sc, rc, group=group)
+        _transport.all_to_all(sc, rc, None, None, group)
         send_counts = sc.cpu().numpy()
         want = torch.from_numpy(self.need - owner * block).to(cdev)      # row numbers inside the owner's block
         give = torch.empty(int(send_counts.sum()), dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(give, want, [int(c) for c in send_counts], [int(c) for c in recv_counts], group=group)
+        _transport.all_to_all(give, want, [int(c) for c in send_counts], [int(c) for c in recv_counts], group)
         self.send_idx = give.to(device)                     # rows of x_local to pack, by destination rank
         self.send_splits = [int(c) for c in send_counts]
         self.recv_splits = [int(c) for c in recv_counts]
@@ -354,12 +362,7 @@ class HaloPlan:
         buf[: self.n_local].copy_(x)
         if self.n_send:
             torch.index_select(x, 0, self.send_idx, out=send)
-        if _via_host(self.group) and x.is_cuda:
-            got = torch.empty((self.n_halo, D), dtype=x.dtype)
-            dist.all_to_all_single(got, send.cpu(), self.recv_splits, self.send_splits, group=self.group)
-            buf[self.n_local:].copy_(got)
-        else:
-            dist.all_to_all_single(buf[self.n_local:], send, self.recv_splits, self.send_splits, group=self.group)
+        _transport.all_to_all(buf[self.n_local:], send, self.recv_splits, self.send_splits, self.group)
         return buf
 
 

@@ -275,14 +275,27 @@ class ShardedTrainStep:
     """train/graph_trainer.py:140-157 (zero_grad, forward, loss, backward, clip_grad_norm_, step)
     for a ShardedTESTModel: every rank passes the SAME global batch; rank r trains on samples
     r, r + W, r + 2W, ..., its loss weighted by its share, so the ranks' losses add up to the
-    global mean."""
+    global mean.
+
+    That weighting reproduces the single-process loss only for losses that are a plain mean over
+    the samples (the trainer's BPR loss, `gather_dot_bpr_loss`, and the log-sigmoid variants).  A
+    masked mean (`bpr_loss(..., mask)` divides by the number of unmasked pairs) or a softmax over
+    the batch is not linear in the split: batches carrying a `mask` are refused.
+
+    With an optimizer that clips inside its update (recommend_amd.optim.FusedClipAdam) the step has
+    no per-parameter launches after the backward pass: one flat all-reduce whose slices BECOME the
+    gradients, then the optimizer's two launches.  `graphed()` records the step, collectives
+    included, as one HIP graph."""
+
+    PER_SAMPLE_KEYS = ("user_ids", "item_ids", "neg_items", "neg_rank", "ratings")
 
     def __init__(self, model: ShardedTESTModel, optimizer: torch.optim.Optimizer,
                  loss_fn: Callable[[Dict, Dict], torch.Tensor], max_grad_norm: Optional[float] = 1.0,
-                 sharded_params: Optional[List[torch.Tensor]] = None):
+                 sharded_params: Optional[List[torch.Tensor]] = None, per_sample_keys=None):
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.max_grad_norm = max_grad_norm
         self.group, self.world, self.rank = model.group, model.world, model.rank
+        self.per_sample_keys = tuple(per_sample_keys or self.PER_SAMPLE_KEYS)
         # as clip_grad_norm_(model.parameters()) and the optimizer see them (train/graph_trainer.py:151-156)
         self.params = [p for p in model.parameters() if p.requires_grad]
         # parameters whose rows are sharded (none in the MMFCN as the reference defines it: its
@@ -292,18 +305,27 @@ class ShardedTrainStep:
         self.replicated = [p for p in self.params if id(p) not in sh]
         self._synced = None      # the replicated parameters some rank has a gradient for
         self.last_grad_norm = None
+        # an optimizer that clips inside its own update and sums the shards' norms over the ranks itself
+        self._opt_clips = hasattr(optimizer, "max_grad_norm")
+        if self._opt_clips:
+            optimizer.max_grad_norm = max_grad_norm
+            if self.sharded and not getattr(optimizer, "_sharded", None):
+                raise ValueError("build the optimizer with sharded_params=... and group=... for row-sharded parameters")
 
     def split(self, batch):
-        """This rank's samples of the global batch (per-sample tensors only; CSR constants pass)."""
+        """This rank's samples of the global batch: the per-sample entries (`per_sample_keys`) are
+        strided, everything else (CSR constants) passes."""
+        if "mask" in batch:
+            raise ValueError("a masked loss is not a plain mean over the samples: it cannot be split over ranks by weight")
         B = batch["user_ids"].shape[0]
         out = {}
         for k, v in batch.items():
-            per_sample = isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == B and k not in ("pos_ptr", "pos_items")
-            out[k] = v[self.rank::self.world] if per_sample else v
+            out[k] = v[self.rank::self.world] if k in self.per_sample_keys else v
         return out, B
 
     def sync_grads(self):
-        """Sum of the replicated parameters' gradients over the ranks: one flat bucket, one all-reduce."""
+        """Sum of the replicated parameters' gradients over the ranks: one flat bucket, one all-reduce;
+        the bucket's slices are the parameters' gradients from then on (no copy back)."""
         if self.world == 1:
             return
         if self._synced is None:
@@ -321,14 +343,15 @@ class ShardedTrainStep:
         flat = torch.cat([g.reshape(-1) for g in grads])
         all_reduce_tensor(flat, dist.ReduceOp.SUM, self.group)
         off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+        for p in self._synced:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
             off += n
 
     def clip(self):
-        """clip_grad_norm_(parameters, max_norm): the norm over replicated gradients is the same on
-        every rank after sync_grads; squared norms of row-sharded gradients are summed over ranks."""
+        """clip_grad_norm_(parameters, max_norm) for optimizers that do not clip themselves: the norm
+        over replicated gradients is the same on every rank after sync_grads; squared norms of
+        row-sharded gradients are summed over ranks."""
         sq = torch.zeros((), dtype=torch.float32, device=self.replicated[0].device)
         for p in self.replicated:
             if p.grad is not None:
@@ -349,8 +372,8 @@ class ShardedTrainStep:
         self.last_grad_norm = total
         return total
 
-    def __call__(self, batch):
-        self.opt.zero_grad(set_to_none=True)
+    def _step(self, batch):
+        """Everything of the step behind zero_grad; returns the global loss (on every rank)."""
         local, B = self.split(batch)
         b_loc = local["user_ids"].shape[0]
         out = self.model(local)
@@ -360,13 +383,34 @@ class ShardedTrainStep:
             loss = (out["user_embeddings"].sum() + out["item_embeddings"].sum()) * 0.0
         loss.backward()
         self.sync_grads()
-        if self.max_grad_norm is not None:
-            self.clip()
-        self.opt.step()
+        if self._opt_clips:
+            self.opt.step()
+            self.last_grad_norm = self.opt.grad_norm
+        else:
+            if self.max_grad_norm is not None:
+                self.clip()
+            self.opt.step()
         total = loss.detach().clone()
         if self.world > 1:
             all_reduce_tensor(total, dist.ReduceOp.SUM, self.group)
         return total
+
+    def __call__(self, batch):
+        self.opt.zero_grad(set_to_none=True)
+        return self._step(batch)
+
+    def graphed(self, example_batch, constants=None, warmup_steps=3, capture=None):
+        """The step as one captured HIP graph (train_step.GraphedStep): every rank records its own
+        graph of the same sequence -- layer kernels, hops, the collectives between them, the flat
+        gradient all-reduce, the optimizer's two launches -- and replays it per global batch.
+        Collectives are capturable on the "nccl" (RCCL) backend only: with any other backend, or
+        capture=False, the returned object runs the step eagerly behind the same interface.
+        The optimizer must be capturable (FusedClipAdam)."""
+        from .train_step import GraphedStep
+        if capture is None:
+            capture = (self.world == 1 and not dist.is_initialized()) or dist.get_backend(self.group) == "nccl"
+        return GraphedStep(self._step, lambda: self.opt.zero_grad(set_to_none=True), example_batch, constants,
+                           warmup_steps, capture=capture)
 
 
 __all__ = ["ShardedGraphConstructor", "ShardedTESTModel", "ShardedTrainStep", "gather_rows"]

@@ -87,6 +87,11 @@ class RankingEvaluator:
             self._dev[device] = st
         return st
 
+    def mask_csr(self, device):
+        """(ptr, items) of the training-pair mask on `device`, or (None, None) without a mask."""
+        st = self._device_state(device)
+        return (st["mask_ptr"], st["mask_items"]) if st["mask_items"].numel() > 0 else (None, None)
+
     def topk(self, user_embeddings, item_embeddings, k, mode="auto"):
         """Ranked top-k item ids per user with the training pairs masked (mode: ops.score_topk)."""
         st = self._device_state(user_embeddings.device)

@@ -661,6 +661,30 @@ def score_topk(U, I, K, mask_ptr=None, mask_items=None, item_id_offset=0, mode="
     return out_s, out_i
 
 
+def score_topk_open_users(U, I, K, mask_ptr=None, mask_items=None):
+    """How many users one filtered ranking of these inputs leaves to the exact kernel (those the
+    candidate filter cannot certify, and the users with the longest training lists, which skip
+    it by rule).  The ranking's results do not depend on it -- its speed does.  Runs one
+    rk_score_topk_filtered_f32 call and synchronises."""
+    _need_cuda(U, I, mask_ptr, mask_items)
+    U, I = _f32c(U.detach()), _f32c(I.detach())
+    if mask_items is None or mask_items.numel() == 0:
+        mask_ptr = mask_items = None
+    n_users, D = U.shape
+    n_items = I.shape[0]
+    lib = _ffi.load()
+    ws = torch.empty(lib.rk_score_topk_ws_bytes(n_users, n_items, D, K) // 4 + 4, dtype=torch.float32, device=U.device)
+    out_s = torch.empty((n_users, K), dtype=torch.float32, device=U.device)
+    out_i = torch.empty((n_users, K), dtype=torch.int32, device=U.device)
+    _ffi.call("rk_score_topk_filtered_f32", ptr(U), c_int32(n_users), ptr(I), c_int32(n_items), c_int32(D),
+              ptr(mask_ptr), ptr(mask_items), c_int32(K), c_int32(0), ptr(out_s), ptr(out_i), ptr(ws),
+              c_size_t(ws.numel() * 4), stream_ptr(U.device))
+    n_open = c_int32(-1)
+    _ffi.call("rk_score_topk_open_users", c_int32(n_users), c_int32(n_items), c_int32(D), c_int32(K), ptr(ws),
+              c_size_t(ws.numel() * 4), stream_ptr(U.device), ctypes.byref(n_open))
+    return int(n_open.value)
+
+
 def rows_topk(scores, K):
     """torch.topk(scores, K, dim=1, largest=True, sorted=True) with ties broken by the lower
     column id.  Returns (values [B,K] fp32, ids [B,K] int32)."""

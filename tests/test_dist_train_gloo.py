@@ -17,25 +17,29 @@ import torch.multiprocessing as mp
 import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-U, I, D, E, B = 37, 30, 64, 260, 24
+U, I, E, B = 37, 30, 260, 24
+# (emb_dim, layer_num): the presets' form, and the large configuration's (emb_dim 128, three layers)
+FORMS = [(64, 2), (128, 3)]
 FEATS = {"image": 96, "text": 32}
 LR = 1e-3   # Adam divides by |g| + 1e-8: gradient elements of that size turn rounding into a fraction of LR
 
 
-class Cfg:
-    class data:
-        num_users, num_items = U, I
+def make_cfg(D, L):
+    class Cfg:
+        class data:
+            num_users, num_items = U, I
 
-    class model:
-        model_name = "MMFCN"
-        modal_num, emb_dim, layer_num, dropout = 2, D, 2, 0.0
+        class model:
+            model_name = "MMFCN"
+            modal_num, emb_dim, layer_num, dropout = 2, D, L, 0.0
 
-    class graph:
-        weight_feature = [None]
-        edge_weight_type, add_self_loops, normalize_adj = "uniform", True, True
+        class graph:
+            weight_feature = [None]
+            edge_weight_type, add_self_loops, normalize_adj = "uniform", True, True
 
-    class system:
-        device = "cpu"
+        class system:
+            device = "cpu"
+    return Cfg
 
 
 def case():
@@ -143,7 +147,7 @@ def gather_dot_loss(out, batch):
     return (-F.logsigmoid(pos.unsqueeze(1) - neg)).mean()
 
 
-def make_reference_state():
+def make_reference_state(Cfg):
     """Parameters of a single-process model, as a plain dict (the product's TESTModel builds its
     graph on the GPU only; here only its parameter names and shapes are needed)."""
     torch.manual_seed(11)
@@ -154,7 +158,7 @@ def make_reference_state():
     return state, m.alphas.detach().clone(), m._first_emb.detach().clone()
 
 
-def _worker(rank, world, port, q, exchange="allgather"):
+def _worker(rank, world, port, q, exchange="allgather", form=(64, 2)):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -162,8 +166,9 @@ def _worker(rank, world, port, q, exchange="allgather"):
     try:
         patch_layers()
         from recommend_amd.dist_train import ShardedTESTModel, ShardedTrainStep
+        Cfg = make_cfg(*form)
         users, items, ratings, feats, batch = case()
-        state, alphas, first = make_reference_state()
+        state, alphas, first = make_reference_state(Cfg)
         model = ShardedTESTModel(Cfg, {}, feats, block_factory=ScipyRowBlock, normalizer=NumpyNormalizer, exchange=exchange)
         model.load_state_dict(state)
         with torch.no_grad():
@@ -189,8 +194,9 @@ def _worker(rank, world, port, q, exchange="allgather"):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("form", FORMS, ids=lambda f: f"D{f[0]}L{f[1]}")
 @pytest.mark.parametrize("exchange", ["allgather", "halo"])
-def test_sharded_training_step_world2_equals_single_process(exchange):
+def test_sharded_training_step_world2_equals_single_process(exchange, form):
     from oracle import graph_oracle, loss_oracle, mmfcn_oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -198,7 +204,7 @@ def test_sharded_training_step_world2_equals_single_process(exchange):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, form)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(2)]
@@ -208,7 +214,7 @@ def test_sharded_training_step_world2_equals_single_process(exchange):
 
     # the single-process step: the oracle's forward and loss, torch's clip and Adam
     users, items, ratings, feats, batch = case()
-    state, alphas, first = make_reference_state()
+    state, alphas, first = make_reference_state(make_cfg(*form))
     N = U + I
     src, dst, w = graph_oracle.build_coo_vectorized(users, items, ratings, U, I, True)
     wn, sq = graph_oracle.normalize(src, dst, w, N)
@@ -216,7 +222,7 @@ def test_sharded_training_step_world2_equals_single_process(exchange):
     p = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
     padded = [torch.cat([torch.zeros(U, f.shape[1]), f]) for f in feats.values()]
     embs = first.unsqueeze(0).expand(2, -1, -1)
-    ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"], embs, [5, 5], alphas, 2, U)
+    ue, ie = mmfcn_oracle.forward(p, A, padded, ["linears.0.linear", "linears.1.linear"], embs, [5, 5], alphas, form[1], U)
     want = loss_oracle.trainer_loss({"user_embeddings": ue, "item_embeddings": ie}, batch)
     want.backward()
     trainable = [v for v in p.values() if v.requires_grad]
@@ -238,9 +244,9 @@ def test_sharded_training_step_world2_equals_single_process(exchange):
                 continue
             scale = float(ref.grad.abs().max()) + 1e-30
             assert float(np.abs(grads[name] - ref.grad.numpy()).max()) <= 2e-5 * scale, (rank, name)
-            assert float(np.abs(params[name] - ref.detach().numpy()).max()) <= 1e-5 * (float(ref.abs().max()) + 1e-30) + 5e-3 * LR, (rank, name)
+            assert float(np.abs(params[name] - ref.detach().numpy()).max()) <= 1e-5 * (float(ref.abs().max()) + 1e-30) + 2e-2 * LR, (rank, name)
             checked += 1
-        assert checked >= 20
+        assert checked >= 13 + 7 * form[1]
     # replicated parameters stay equal across ranks
     for name in results[0][4]:
         assert np.array_equal(results[0][4][name], results[1][4][name]), name
