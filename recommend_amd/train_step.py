@@ -39,7 +39,7 @@ class GraphedStep:
         ops.set_dropout_step_tensor(self.step_counter)
         self.graph = None
         # warm-up on a side stream, as graph capture requires (allocator pools, lazy state)
-        s = torch.cuda.Stream(device=dev)
+        s = self._stream = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(warmup_steps):
@@ -64,7 +64,14 @@ class GraphedStep:
         """Runs one step on `batch`; returns the loss (a device scalar that the next call
         overwrites)."""
         if self.graph is None or any(tuple(batch[k].shape) != self.shapes[k] for k in self.shapes):
-            return self._eager(batch)
+            # on the stream the recorded step's autograd nodes were created on (gradient accumulators
+            # outlive an iteration and remember their stream)
+            cur = torch.cuda.current_stream(self._stream.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                loss = self._eager(batch)
+            cur.wait_stream(self._stream)
+            return loss
         for k, dst in self.static.items():
             dst.copy_(batch[k], non_blocking=True)
         self.graph.replay()

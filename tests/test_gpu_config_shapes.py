@@ -16,11 +16,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("D", [64, 128])        # 128 is the Clothing preset's emb_dim (config.py:201)
 @pytest.mark.parametrize("mode", ["auto", "filter"])
-def test_clothing_shape_item_sharded_topk(mode):
+def test_clothing_shape_item_sharded_topk(mode, D):
     d = synth.make_named("clothing")
     rng = np.random.default_rng(2)
-    D = 64
     # half-integer grid: plenty of exact score ties, so "lower id wins" is exercised across shards
     ue = (np.round(rng.standard_normal((d.n_users, D)) * 2) / 8).astype(np.float32)
     ie = (np.round(rng.standard_normal((d.n_items, D)) * 2) / 8).astype(np.float32)
@@ -50,10 +50,11 @@ def test_clothing_shape_item_sharded_topk(mode):
             assert torch.equal(ms, want_s), (K, world)
 
 
-@pytest.mark.parametrize("shape", ["sports", "elec"])
-def test_model_forward_vs_oracle_at_shape(shape):
+# (shape, emb_dim of its preset: config.py:201,212,223)
+@pytest.mark.parametrize("shape,D", [("sports", 64), ("clothing", 128), ("elec", 64)])
+def test_model_forward_vs_oracle_at_shape(shape, D):
     d = synth.make_named(shape)
-    U, I, D = d.n_users, d.n_items, 64
+    U, I = d.n_users, d.n_items
     image, text = synth.make_features(I)[:2]
     feats = {"image": torch.from_numpy(image), "text": torch.from_numpy(text)}
 

@@ -129,11 +129,11 @@ def test_row_sharded_parameters_clip_by_the_norm_over_all_ranks():
         want_norm = float(torch.linalg.vector_norm(torch.cat([q.grad.reshape(-1) for q in ref])))
         torch.nn.utils.clip_grad_norm_(ref, 0.7)
         topt.step()
-        for r in ranks:
+        for ri, r in enumerate(ranks):
             for p, gr in zip(r["params"][:-1], grads[:-1]):
                 p.grad = gr.clone().to(DEV)
             r["params"][-1].grad = grads[-1][r["lo"]:r["hi"]].clone().to(DEV)
-            pending[ranks.index(r)] = (r["params"][-1].grad.double() ** 2).sum().float().reshape(1)
+            pending[ri] = (r["params"][-1].grad.double() ** 2).sum().float().reshape(1)
         for r in ranks:
             r["opt"].step()
             assert abs(float(r["opt"].grad_norm) - want_norm) <= 2e-5 * want_norm
