@@ -41,9 +41,10 @@ class GraphedStep:
         # warm-up on a side stream, as graph capture requires (allocator pools, lazy state)
         s = self._stream = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
+        self.warmup_losses = []     # the warm-up steps are real training steps on the example batch
         with torch.cuda.stream(s):
             for _ in range(warmup_steps):
-                self._eager(self.static)
+                self.warmup_losses.append(self._eager(self.static).clone())
         torch.cuda.current_stream(dev).wait_stream(s)
         if not capture:
             return

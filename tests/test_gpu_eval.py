@@ -556,3 +556,97 @@ def test_evaluator_with_k_50_vs_oracle():
     for k in (10, 50):
         for m in METRICS:
             assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)
+
+
+def _open_users(ue, ie, K, ptr, cols):
+    return ops.score_topk_open_users(ue, ie, K, ptr, cols)
+
+
+def test_filter_certifies_popularity_skewed_embeddings():
+    """What an evaluator sees after training is not Gaussian: item norms follow popularity (here
+    spread 10x along a Zipf curve), user vectors lean towards the popular direction, and the best
+    scores of a user crowd together.  The certificate's error bound grows with the largest item
+    norm, so this is the input on which a weak filter would show: the filtered ranking must still
+    be the exact kernel's bit for bit AND leave few users to the exact pass."""
+    U, I, D, K = 20000, 7000, 64, 20
+    g = torch.Generator().manual_seed(77)
+    pop = 1.0 / torch.arange(1, I + 1, dtype=torch.float32) ** 0.5          # Zipf-like popularity
+    norms = 0.1 * (1.0 + 9.0 * (pop - pop.min()) / (pop.max() - pop.min()))  # 0.1 .. 1.0: a 10x spread
+    direction = torch.nn.functional.normalize(torch.randn(D, generator=g), dim=0)
+    ie = torch.nn.functional.normalize(torch.randn(I, D, generator=g) + 1.5 * direction, dim=1) * norms[:, None]
+    ie = ie[torch.randperm(I, generator=g)]
+    ue = torch.randn(U, D, generator=g) * 0.05 + direction * (0.3 * torch.rand(U, 1, generator=g))
+    ue, ie = ue.to(DEV), ie.to(DEV)
+    rng = np.random.default_rng(7)
+    ptr, mcols = pairs_to_csr(rng.integers(0, U, 8 * U), rng.integers(0, I, 8 * U), U)
+    mp, mc = dev(ptr), dev(mcols)
+    n_open = _open_users(ue, ie, K, mp, mc)
+    assert 0 <= n_open <= 1024, n_open
+    fs, fi = ops.score_topk(ue, ie, K, mp, mc, mode="filter")
+    es, ei = ops.score_topk(ue, ie, K, mp, mc, mode="exact")
+    assert torch.equal(fi, ei) and torch.equal(fs.view(torch.int32), es.view(torch.int32))
+
+
+def test_filter_certifies_the_embeddings_of_a_trained_model():
+    """The MMFCN after 200 training steps at the Baby shape (graphed step, dropout on, the
+    preset's batch size): evaluation of ITS embeddings through the filter equals the exact
+    kernel's bits and the filter settles all but a few users."""
+    from recommend_amd.loss import gather_dot_bpr_loss
+    from recommend_amd.model import ModelFactory
+    from recommend_amd.optim import FusedClipAdam
+    from recommend_amd.sampler import NegativeSampler, TrainBatchLoader, build_user_csr
+    from recommend_amd.train_step import GraphedTrainStep
+    d = synth.make_named("baby")
+    U, I = d.n_users, d.n_items
+
+    class C:
+        class data:
+            num_users, num_items = U, I
+        class model:
+            model_name = "MMFCN"
+            modal_num, emb_dim, layer_num, dropout = 2, 64, 2, 0.3
+        class graph:
+            weight_feature = [None]
+            edge_weight_type, add_self_loops, normalize_adj = "uniform", True, True
+        class system:
+            device = DEV
+
+    g = torch.Generator().manual_seed(3)
+    feats = {"image": torch.randn(I, 512, generator=g), "text": torch.nn.functional.normalize(torch.randn(I, 96, generator=g))}
+    torch.manual_seed(3)
+    model = ModelFactory.create_Model(C, {}, feats).to(DEV)
+    tu, ti, tr = d.split(0)
+    model.build_graph((tu, ti, tr))
+    model.creat_feature_weight()
+    p, it = build_user_csr(d.users, d.items, U)
+    sampler = NegativeSampler(p, it, I, seed=42)
+    dp, di = sampler.device_csr(DEV)
+    loader = TrainBatchLoader(tu, ti, tr, 2048, sampler, device=DEV, resolve_on_host=False)
+    opt = FusedClipAdam(model.parameters(), lr=1e-3)
+    model.train()
+    try:
+        step, done, first_loss = None, 0, None
+        while done < 200:
+            for batch in loader:
+                if step is None:
+                    step = GraphedTrainStep(model, opt, gather_dot_bpr_loss, batch, constants={"pos_ptr": dp, "pos_items": di})
+                    done += 3
+                loss = step(batch)
+                first_loss = float(loss) if first_loss is None else first_loss
+                done += 1
+                if done >= 200:
+                    break
+        assert float(loss) < first_loss                       # it did train
+    finally:
+        ops.set_dropout_step_tensor(None)
+    model.eval()
+    with torch.no_grad():
+        out = model({})
+    ue, ie = out["user_embeddings"].contiguous(), out["item_embeddings"].contiguous()
+    ptr, mcols = pairs_to_csr(tu, ti, U)
+    mp, mc = dev(ptr), dev(mcols)
+    n_open = _open_users(ue, ie, 20, mp, mc)
+    assert 0 <= n_open <= 1024, n_open
+    fs, fi = ops.score_topk(ue, ie, 20, mp, mc, mode="filter")
+    es, ei = ops.score_topk(ue, ie, 20, mp, mc, mode="exact")
+    assert torch.equal(fi, ei) and torch.equal(fs.view(torch.int32), es.view(torch.int32))
