@@ -379,7 +379,11 @@ int rk_bpr_bwd_f32(const float *U, const float *I, int32_t D,
  * first call there.  B <= rk_bpr_fwd_noalloc_max_batch() (65,536 samples), otherwise
  * RK_ERR_UNSUPPORTED.  No hipMalloc / hipFree happens in the call.  All calls on one
  * GPU share the array: two calls in flight on different streams of one GPU race
- * (calls on one stream are ordered and safe; nothing needs clearing between them). */
+ * (calls on one stream are ordered and safe; nothing needs clearing between them).
+ * The FIRST call on a device looks the array's address up (hipGetDevice +
+ * hipGetSymbolAddress under a mutex, which may load the code object): make it outside
+ * any stream capture -- one eager call per device is the warm-up; every later call
+ * enqueues two kernels and nothing else, and can be recorded in a HIP graph. */
 int64_t rk_bpr_fwd_noalloc_max_batch(void);
 int rk_bpr_fwd_noalloc_f32(const float *U, const float *I, int32_t D,
                            const int64_t *users, const int64_t *pos, int64_t *neg,

@@ -79,9 +79,6 @@ def gather_dot_bpr_loss(outputs, batch):
                               item_ids.to(dev), neg_items_ids.to(dev))
 
 
-__all__ = ["bpr_loss", "gather_dot_bpr_loss"]
-
-
 def mmgcn_loss(outputs, batch):
     """mmgcn_loss (evalue/loss.py:153-173, = model/Main_Model.py:672-692): one negative per
     sample, -mean(log(sigmoid(pos - neg))) in the reference's two-step form, plus the
@@ -97,11 +94,16 @@ def mmgcn_loss(outputs, batch):
     batch_users, pos_items, neg_items = batch_users.to(dev), pos_items.to(dev), neg_items.to(dev)
     loss = ops.bpr_gather_dot(user_h, item_h, batch_users, pos_items, neg_items.reshape(-1, 1),
                               mode=ops.LOSS_LOG_SIGMOID)
-    user_tensor = batch_users.repeat_interleave(2)
-    item_tensor = torch.stack((pos_items, neg_items)).t().contiguous().view(-1)
-    reg_embedding_loss = (id_embedding[user_tensor] ** 2 + id_embedding[item_tensor] ** 2).mean()
-    reg_embedding_loss = reg_embedding_loss + (outputs["pres"] ** 2).mean()
-    return loss + 0 * reg_embedding_loss
+    # The reference adds 0 * (mean of squared id-embedding rows of the batch + mean(pres^2)): a term whose
+    # only effect is to turn the loss into NaN when one of those values is not finite (or its square
+    # overflows).  Its value and gradient are zero otherwise, so no gradient graph is built for it,
+    # and the squares of the batch's rows are reduced without materialising the interleaved index
+    # tensors.
+    with torch.no_grad():
+        idd = id_embedding.detach()
+        reg = (idd[batch_users] ** 2).mean() + (idd[pos_items] ** 2).mean() + (idd[neg_items] ** 2).mean()
+        reg = reg + (outputs["pres"].detach() ** 2).mean()
+    return loss + 0 * reg
 
 
 def compute_info_bpr_loss(a_embeddings, b_embeddings, pos_edges, neg_items, reduction="mean",
@@ -133,3 +135,6 @@ def sgrec_loss(result, batch, reg_weight=0.0):
                               mode=ops.LOSS_LOG_SIGMOID)
     reg_loss = torch.mean(result["ori_u_emb"] ** 2) + torch.mean(result["ori_i_emb"] ** 2)
     return loss + reg_weight * reg_loss
+
+
+__all__ = ["bpr_loss", "gather_dot_bpr_loss", "mmgcn_loss", "compute_info_bpr_loss", "sgrec_loss"]

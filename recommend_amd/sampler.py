@@ -33,40 +33,67 @@ class NegativeSampler:
     """random.sample over the ascending list of items the user never touched
     (graph_data_loader.py:373-397), with CPython's generator state kept here."""
 
-    def __init__(self, pos_ptr, pos_items, n_items, seed=42, neg_ratio=1):
+    def __init__(self, pos_ptr, pos_items, n_items, seed=42, neg_ratio=1, all_items=None,
+                 cache_entries=1 << 24):
+        """all_items: the item ids that count as candidates when not every id below n_items occurs
+        in the interaction table (see below); cache_entries: how many candidate ids may be kept
+        for the users whose candidate order is emulated (4 bytes each; users beyond the budget
+        are emulated per sample)."""
         if neg_ratio <= 0:
             raise ValueError("Negative ratio must be greater than zero")
         self.pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int32)
         self.pos_items = np.ascontiguousarray(pos_items, dtype=np.int32)
         self.n_items = int(n_items)
+        self.cache_entries = int(cache_entries)
+        self.item_ids = None      # rank -> item id when the candidates are a subset of range(n_items)
         # The reference draws from all_items = the ids that OCCUR in the interaction table
         # (data/graph_data_loader.py:173); this sampler ranks candidates over range(n_items).  The
         # two agree (and the random stream stays the reference's) only if every id occurs.
-        present = np.zeros(self.n_items, bool)
-        present[self.pos_items[(self.pos_items >= 0) & (self.pos_items < self.n_items)]] = True
-        if not present.all():
-            missing = np.flatnonzero(~present)
-            raise ValueError(
-                f"{missing.size} item ids below n_items={self.n_items} never occur in the interaction table "
-                f"(first: {missing[:5].tolist()}); the reference samples negatives from the ids that occur, "
-                "so its candidate lists and random stream differ from range(n_items): remap item ids densely")
+        if all_items is None:
+            present = np.zeros(self.n_items, bool)
+            present[self.pos_items[(self.pos_items >= 0) & (self.pos_items < self.n_items)]] = True
+            if not present.all():
+                missing = np.flatnonzero(~present)
+                raise ValueError(
+                    f"{missing.size} item ids below n_items={self.n_items} never occur in the interaction table "
+                    f"(first: {missing[:5].tolist()}); the reference samples negatives from the ids that occur, "
+                    "so its candidate lists and random stream differ from range(n_items): remap item ids densely, "
+                    "or pass all_items=<the ids that occur> to sample from exactly those")
+        else:
+            # Sparse id space, or positives from a part of the table: candidates are `all_items`
+            # minus the user's positives, in ASCENDING id order.  The reference lists them in the
+            # slot order of its Python set, which for sparse ids is not ascending and is not
+            # reproduced here: the same candidate sets and the same random stream, other picks.
+            ids = np.unique(np.asarray(all_items, dtype=np.int64))
+            if ids.size == 0 or ids[0] < 0:
+                raise ValueError("all_items must hold non-negative item ids")
+            self.item_ids = ids
+            lens = np.diff(self.pos_ptr.astype(np.int64))
+            rows = np.repeat(np.arange(lens.shape[0]), lens)
+            pos = self.pos_items.astype(np.int64)
+            where = np.searchsorted(ids, pos)
+            where[where >= ids.size] = ids.size - 1
+            known = ids[where] == pos                  # positives outside all_items are no candidates anyway
+            new_ptr = np.zeros(lens.shape[0] + 1, np.int64)
+            np.cumsum(np.bincount(rows[known], minlength=lens.shape[0]), out=new_ptr[1:])
+            self.pos_ptr = new_ptr.astype(np.int32)
+            self.pos_items = np.ascontiguousarray(where[known], dtype=np.int32)   # ranks: ascending per user
+            self.n_items = int(ids.size)
         self.neg_ratio = int(neg_ratio)
         self.state = np.zeros(625, np.uint32)
         self.seed(seed)
         self._dev = {}
         self._cache_orders()
 
-    # candidate-order entries kept for the users whose lists are emulated (1 GiB of ids)
-    CACHE_ENTRIES = 1 << 28
-
     def _cache_orders(self):
         """Users holding a quarter of all items or more have their candidates listed in CPython's
         hash-table order, which costs a pass over every item id to rebuild; there are few of them
-        and they recur in batch after batch, so their orders are built once here."""
+        and they recur in batch after batch, so their orders are built once here (up to
+        `cache_entries` ids in all)."""
         lens = np.diff(self.pos_ptr.astype(np.int64))
         heavy = np.flatnonzero((lens >= (self.n_items >> 2)) & (lens < self.n_items))
         sizes = self.n_items - lens[heavy]
-        keep = np.cumsum(sizes) <= self.CACHE_ENTRIES
+        keep = np.cumsum(sizes) <= self.cache_entries
         heavy, sizes = heavy[keep], sizes[keep]
         self.cached_users = np.ascontiguousarray(heavy, dtype=np.int64)
         self.cached_ptr = np.zeros(heavy.size + 1, np.int64)
@@ -94,10 +121,15 @@ class NegativeSampler:
                   c_int32(self.neg_ratio), ptr(self.pos_ptr), ptr(self.pos_items),
                   c_int32(self.n_items), ptr(self.cached_users), ptr(self.cached_ptr), ptr(self.cached_order),
                   c_int32(self.cached_users.shape[0]), ptr(ranks), ptr(neg))
+        if neg is not None and self.item_ids is not None:
+            neg = self.item_ids[neg]
         return ranks, neg
 
     def device_csr(self, device):
         """User->positives CSR in HBM for the in-kernel negative lookup."""
+        if self.item_ids is not None:
+            raise ValueError("the in-kernel negative lookup ranks candidates over range(n_items); with all_items=... "
+                             "resolve the negatives on the host (TrainBatchLoader(resolve_on_host=True))")
         device = torch.device(device)
         if device not in self._dev:
             self._dev[device] = (torch.from_numpy(self.pos_ptr).to(device),

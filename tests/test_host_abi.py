@@ -230,3 +230,43 @@ def test_cached_candidate_orders_leave_the_sampler_stream_unchanged(R):
         cands = list(all_items - pos)
         want = random.sample(cands, R) if len(cands) >= R else random.choices(cands, k=R)
         assert neg_c[b].tolist() == want
+
+
+def test_sampler_over_a_sparse_id_space_and_its_cache_budget():
+    """Item ids with holes (or positives from a part of the table): without `all_items` the sampler
+    refuses -- the reference's candidate list is then its set's slot order, not range(n_items) --
+    and with it the candidates are exactly all_items minus the user's positives, drawn by the same
+    random.sample arithmetic over their ascending list.  A zero cache budget changes nothing but
+    where the heavy users' candidate orders are rebuilt."""
+    import random
+    rng = np.random.default_rng(4)
+    ids = np.sort(rng.choice(500, 120, replace=False))           # 120 of 500 ids occur
+    U = 40
+    users = rng.integers(0, U, 900)
+    items = ids[rng.integers(0, len(ids), 900)]
+    items[:110] = ids[:110]
+    users[:110] = 3                                              # a heavy user: candidate order emulated
+    p, it = build_user_csr(users, items, U)
+    with pytest.raises(ValueError, match="never occur"):
+        NegativeSampler(p, it, 500, seed=1)
+    batch = np.concatenate([rng.integers(0, U, 60), [3, 3, 3]])
+    got = {}
+    for budget in (1 << 24, 0):
+        s = NegativeSampler(p, it, 500, seed=1, neg_ratio=2, all_items=ids, cache_entries=budget)
+        assert (s.cached_users.size > 0) == (budget > 0)
+        ranks, neg = s.sample(batch)
+        got[budget] = neg
+        for u, row in zip(batch, neg):
+            assert set(row.tolist()) <= set(ids.tolist()) - set(it[p[u]:p[u + 1]].tolist())
+        with pytest.raises(ValueError, match="resolve the negatives on the host"):
+            s.device_csr("cpu")
+    np.testing.assert_array_equal(got[1 << 24], got[0])
+    # light users: random.sample over the ascending candidate list, the same stream
+    random.seed(1)
+    for u, row in zip(batch, got[0]):
+        pos = set(it[p[u]:p[u + 1]].tolist())
+        cands = [int(i) for i in ids if int(i) not in pos]
+        if len(pos) < (len(ids) >> 2):
+            assert random.sample(cands, 2) == row.tolist()
+        else:       # (heavy user: CPython's order differs from ascending; consume the same draws)
+            random.sample(cands, 2)

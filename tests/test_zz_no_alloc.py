@@ -68,6 +68,32 @@ def test_noalloc_bpr_forward_matches_workspace_form_twice():
             assert torch.equal(a, b)
 
 
+def test_noalloc_bpr_forward_recorded_in_a_hip_graph():
+    """The callers this entry point is for: after one eager call on the device (which looks the
+    built-in array's address up), a call recorded in a HIP graph and replayed on new inputs gives
+    the workspace form's bits."""
+    n_users, n_items, D, B, R = 2000, 700, 64, 1500, 2
+    dev = torch.device("cuda", 0)
+    U, I, users, pos, neg, rank, pos_ptr, pos_items, mask = _inputs(B, R, n_users, n_items, D, 5, False)
+    _run("rk_bpr_fwd_noalloc_f32", U, I, users, pos, neg, rank, pos_ptr, pos_items, mask, n_items)   # eager warm-up
+    x = torch.zeros((B, R), device=dev)
+    out = torch.zeros(2, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        _ffi.call("rk_bpr_fwd_noalloc_f32", ptr(U), ptr(I), c_int32(D), ptr(users), ptr(pos), ptr(neg), c_int64(B),
+                  c_int32(R), ptr(mask), None, None, None, c_int32(n_items), ptr(x), ptr(out), stream_ptr(dev))
+    for seed in (6, 7):       # new inputs in the recorded buffers, one replay each
+        U2, I2, users2, pos2, neg2, _r, _pp, _pi, mask2 = _inputs(B, R, n_users, n_items, D, seed, False)
+        for dst, src in ((U, U2), (I, I2), (users, users2), (pos, pos2), (neg, neg2), (mask, mask2)):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = _run("rk_bpr_fwd_f32", U, I, users, pos, neg, None, pos_ptr, pos_items, mask, n_items)
+        assert torch.equal(out.cpu(), ref[0]) and torch.equal(x.cpu(), ref[1])
+
+
 def test_noalloc_bpr_forward_rejects_oversize_batch():
     lim = int(_ffi.load().rk_bpr_fwd_noalloc_max_batch())
     dev = torch.device("cuda", 0)
