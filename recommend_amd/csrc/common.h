@@ -40,4 +40,14 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;
 
+// v_permlane32_swap: lanes 32..63 of `lo` and lanes 0..31 of `hi` change places.  Through the
+// compiler's builtin, not inline assembly: the instruction reads both operands as VALU sources, and
+// the wait states it needs behind an MFMA or a vector instruction that has just written them are
+// placed by the compiler's hazard recogniser, which does not look inside inline assembly.
+__device__ __forceinline__ void swap_halves32(float &lo, float &hi) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+  lo = __uint_as_float(r[0]);
+  hi = __uint_as_float(r[1]);
+}
+
 }  // namespace rk

@@ -162,6 +162,11 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ M, int64_t 
 // DMA in flight (vmcnt(0)), which drains the prefetch of the next tile in the middle of this one.
 // Written this way the pass knows nothing of the DMAs, and the kernel's own s_waitcnt in front of
 // the first read of each tile is the synchronisation.  `row0` and `dst` are wave-uniform.
+// Rules relied on: one wait state between the scalar write of M0 and the DMA that reads it (the
+// s_nop 0 inside the statement); completion by vmcnt in issue order (do_tile's vmcnt(0/8/16) through
+// the s_waitcnt builtin); the LDS tile a DMA overwrites has been read back completely (the
+// lgkmcnt(0) in front of every re-staging).  No register destination, so nothing can be moved
+// ahead of those waits by the register allocator.
 __device__ __forceinline__ void stage_rows_raw(const float *__restrict__ M, int64_t row0, int64_t n_rows,
                                                float *dst, uint32_t lane_off) {
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(

@@ -174,18 +174,15 @@ __global__ __launch_bounds__(256, 1) void wide_score_topk_kernel(
     for (int j = 0; j < GT; ++j) {
       // lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in
       // acc_b; after the swap lane l holds, for user ubase+l, rows (r&3)+8*(r>>2) in lo[r] and
-      // rows 4+(r&3)+8*(r>>2) in hi[r].  The s_nop pair covers the wait states between the last
-      // MFMA pass and a vector read of its result, which the compiler does not insert in front
-      // of inline assembly.
-      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc_a[j]), "+a"(acc_b[j]));
+      // rows 4+(r&3)+8*(r>>2) in hi[r]  (the compiler's builtin: it places the wait states behind
+      // the last MFMA pass)
       float lo[16], hi[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         lo[r] = acc_a[j][r];
         hi[r] = acc_b[j][r];
+        rk::swap_halves32(lo[r], hi[r]);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
       const int32_t item0 = (g * GT + j) * TI;
       if (item0 < n_b) {                 // uniform
 #pragma unroll

@@ -191,7 +191,13 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(
   // (GPW lane groups striding the slots, then a fixed shuffle tree), so the bits do not depend on
   // which chunk came last.  A release/acquire fence pair would do as well, but at agent scope
   // the release writes back the whole L2 -- with the output rows of the hop in it -- once per chunk.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // HARDWARE-CONTRACT CODE, not HIP memory-model code: the ordering "partial stores reach memory,
+  // then the ticket is drawn" rests on (a) agent-scope relaxed atomic stores being written through
+  // to memory on gfx950 and counted by vmcnt until they are, (b) this s_waitcnt vmcnt(0) in every
+  // storing wavefront, (c) the workgroup barrier in front of the one thread that draws the ticket.
+  // The HIP memory model would ask for a release fence here; see the comment above for its cost.
+  __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
+  asm volatile("" ::: "memory");                // (compiler barrier only: no instruction)
   __syncthreads();                              // also: everybody is done reading red[]
   int32_t *flag = reinterpret_cast<int32_t *>(&red[0][0]);
   if (tid == 0) {

@@ -315,6 +315,12 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
   // of every first read of a tile is the only synchronisation, and it is sufficient.  More
   // operations in the in-order counter than the compiler knows of only make its own vmcnt(N)
   // waits stronger.
+  // Hazard rules these two statements rely on: (1) a scalar write of M0 needs one wait state before
+  // an LDS-DMA reads it: the s_nop 0 inside the statement; (2) completion is counted by vmcnt in
+  // issue order: the kernel's own s_waitcnt vmcnt(N) (the builtin, visible to the compiler) stands
+  // in front of the first read of every tile; (3) the LDS range a DMA overwrites has been read
+  // completely before it is issued: an lgkmcnt(0) (and, for the shared ring, the stage barrier)
+  // precedes every issue.  No VGPR destination: nothing for the register allocator to move early.
   auto dma_piece = [&](const char *base, uint32_t off, uint32_t lds_addr) {   // uniform base + lane offset
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  : : "v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
@@ -369,6 +375,8 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     do {
       const bool has = q < qc;
       uint32_t qs, qid;
+      // (self-contained: its own lgkmcnt(0) inside the statement, early-clobber outputs; LDS
+      // operations of a wavefront complete in order, so it sees the ds_write2 statements before it)
       asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(qs), "=&v"(qid) : "v"(qbase + (uint32_t)q * 256u));
       list.insert(has ? __uint_as_float(qs) : -INFINITY, (int32_t)qid);
@@ -384,8 +392,9 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
   // all; only then are the four scores parked, branch free: the store always happens and the
   // slot advances only for a candidate.
   auto consider4 = [&](float v0, float v1, float v2, float v3, int32_t id0) {
-    // (v_max3 written out: fmaxf() on values that come out of inline assembly costs a
-    // canonicalising v_max per operand; a NaN operand is ignored either way)
+    // (v_max3 written out: fmaxf() on values the compiler does not know to be canonical costs a
+    // canonicalising v_max per operand; a NaN operand is ignored either way.  The operands are results
+    // of the half swap, a vector instruction: no wait states are owed between the two.)
     float m;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(v0), "v"(v1), "v"(v2));
     asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(v3));
@@ -394,6 +403,7 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
     const float v[4] = {v0, v1, v2, v3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      // (address and data are vector-ALU results: ordinary register dependencies, interlocked by the hardware)
       asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:8"
                    : : "v"(qbase + (uint32_t)qc * 256u), "v"(v[i]), "v"(id0 + i));
       qc += v[i] > thr ? 1 : 0;
@@ -413,20 +423,15 @@ __global__ __launch_bounds__(256, wg_per_cu(KPAD, DC, FILTER)) void score_topk_k
   // Lane l holds rows (r&3)+8*(r>>2)+4*half of user col in acc_a and of user 32+col in acc_b.
   // After the swap every lane holds, for ITS user (ubase + lane), rows (r&3)+8*(r>>2) in lo[r]
   // and rows 4+(r&3)+8*(r>>2) in hi[r].
-  // The swap is written as inline assembly: the compiler's builtin returns its first result for
-  // both halves.  The s_nop pair covers the 18 wait states between the last MFMA pass and a
-  // VALU read of its result, which the compiler does not insert in front of inline assembly.
-  // (the accumulators are operands of the s_nop statement so that it stays behind the MFMAs)
+  // (rk::swap_halves32 is the compiler's builtin: the wait states between the last MFMA pass and
+  // this first vector read of its result are the compiler's to place)
   auto swap_halves = [&](floatx16 &acc_a, floatx16 &acc_b, float (&lo)[16], float (&hi)[16]) {
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a), "+v"(acc_b));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       lo[r] = acc_a[r];
       hi[r] = acc_b[r];
+      rk::swap_halves32(lo[r], hi[r]);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo[r]), "+v"(hi[r]));
   };
   // scores of tile t that do not rank as computed: rows past the end of the item table (never),
   // training interactions of this lane's user (the mask score)

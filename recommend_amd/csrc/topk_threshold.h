@@ -57,6 +57,10 @@ struct HalfTiles {
 
 // This wavefront's quarter of item tile t into dst (LDS) by LDS-DMA; see score_topk_kernel for why
 // the DMA is inline assembly and what the offsets are.
+// LDS-DMA written as inline assembly, as in topk_kernel.h and for the reason given there.  Rules
+// relied on: one wait state between the scalar write of M0 and the DMA that reads it (the s_nop 0);
+// completion by vmcnt, waited for by the callers' own s_waitcnt (the builtin) + stage barrier in
+// front of a stage's first read; every reader of the stage a DMA overwrites has passed that barrier.
 template <int DC>
 __device__ __forceinline__ void issue_half_tile(const float *__restrict__ Iemb, int32_t n_items, int32_t t,
                                                 float *dst, uint32_t &lane_off, int pbase) {
@@ -165,8 +169,11 @@ struct StreamState {
       acc_a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fi[kb & 1], uha[kb], kb == 0 ? zero : acc_a, 0, 0, 0);
       acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(fi[kb & 1], uhb[kb], kb == 0 ? zero : acc_b, 0, 0, 0);
     }
-    // 18 wait states between the last MFMA pass and a vector read of its result, which the
-    // compiler does not insert in front of inline assembly
+    // Hazard rule: 18 wait states between the last pass of a 32x32 MFMA and a vector-ALU read of
+    // its result.  The first readers of these accumulators are single-instruction inline assembly
+    // statements (RK_VMAX, RK_MASK_IF_BIT below), in front of which the compiler places none: the
+    // s_nop pair (20 wait states) stands here for them.  The accumulators are operands of the
+    // statement so that it stays behind the MFMAs.
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc_a), "+v"(acc_b));
   }
 };
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(256, DC == 1 ? 3 : 2) void collect_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float x = acc_a[r], y = acc_b[r];
-        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+        rk::swap_halves32(x, y);
         acc_a[r] = x;
         acc_b[r] = y;
       }
