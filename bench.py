@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--cpu-users", type=int, default=8192, help="users in the CPU baseline sample (0: skip)")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--spmm-reps", type=int, default=200, help="SpMM launches per timing")
+    ap.add_argument("--scaleup-slice", type=int, default=1,
+                    help="1: also time the hop on one rank's row block of the large configuration (8 GB of device memory, ~10 s)")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="short run for a rocprofv3 --pmc pass: few repetitions, no exact-kernel, epoch or CPU leg; "
                          "prints how many calls of each kind were made so counters can be divided per call")
@@ -372,6 +374,39 @@ def main():
                      "ms_per_launch": round(ms_spmm, 5),
                      "algorithmic": f"nnz*8 + (N+1)*4 + 2*N*D*4 = {spmm_bytes} B per hop"}
     ms_spmm_t = event_ms(lambda: ops.spmm_raw(gc.graph.bwd, h, out=buf), args.spmm_reps)
+    roofline_spmm["note"] = ("at this shape the hop is bound by the L1 miss queues (63 requests of 128 B in flight per CU at "
+                             "~600 cycles each), not by HBM bytes: with every gather an L1 hit the same kernel takes 52 us = "
+                             "0.37 of the HBM peak, which is the ceiling of 256-B fp32 row gathers on this chip; 0.60 is "
+                             "not reachable at fp32")
+
+    # the same kernel on what ONE of eight ranks holds of the large configuration (10M x 2M x 500M,
+    # emb_dim 128: 1.5M rows, 512-B rows gathered from a 6.1 GB layer): checked against float64 on a
+    # sample of rows; bytes = index arrays + every distinct layer row named, once + output.  The last
+    # rank's block (cold item rows reading user rows, nearly all distinct) is the one HBM bounds; the
+    # first rank's (user rows reading the Zipf-popular item rows) is served from the caches.
+    roofline_slice = None
+    if args.scaleup_slice and not dist_on and not args.pmc_pass:
+        from tools.scaleup_sizing import rank_slice_hop
+
+        def slice_line(rank, what):
+            r = rank_slice_hop(dev, rank)
+            if r["max_rel_err_vs_float64"] > 1e-5:
+                raise RuntimeError(f"scale-up slice hop differs from float64 by {r['max_rel_err_vs_float64']:.2e}")
+            gbs_s = r["compulsory_bytes"] / (r["ms"] * 1e-3) / 1e9
+            log(f"[bench] scale-up slice, rank {rank}: {r['ms']:.3f} ms, {gbs_s:.0f} GB/s of compulsory bytes")
+            return {"kernel": f"spmm_rows_kernel<32> on the row block of rank {rank} of 8 of the 10M x 2M x 500M configuration ({what})",
+                    "bound": "hbm", "achieved": round(gbs_s, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs_s / HBM_PEAK_GBS, 4), "ms_per_launch": round(r["ms"], 4),
+                    "rows": r["rows"], "nnz": r["nnz"], "distinct_rows_gathered": r["distinct_rows_gathered"],
+                    "algorithmic": f"nnz*8 + (rows+1)*4 + distinct_rows*D*4 + rows*D*4 = {r['compulsory_bytes']} B per hop",
+                    "gather_level_GBs": round(r["gather_level_bytes"] / (r["ms"] * 1e-3) / 1e9, 1),
+                    "max_rel_err_vs_float64": float(f"{r['max_rel_err_vs_float64']:.3g}")}
+        roofline_slice = slice_line(7, "cold item rows gathering user rows: nearly every gathered row is a different one")
+        roofline_slice["traffic"] = None
+        roofline_slice["traffic_note"] = ("profiles/r03_pmc_scaleup_slices.txt: 20.3 GB per launch leave the L2 (every gather of a "
+                                          "row that 3.7 edges of the block name goes to memory: 5.2 TB/s = 0.65 of the HBM peak on the "
+                                          "traffic it causes, 0.22 on the bytes it cannot avoid; the graph has no locality to reuse)")
+        roofline_slice["user_rows_block"] = slice_line(0, "user rows gathering the Zipf-popular item rows, half of them L2 hits")
 
     # ---------------------------------------------------------------- one training epoch
     epoch = trained = None
@@ -475,6 +510,7 @@ def main():
                                        f"emb_dim {D}, full-rank top-20 + metrics@5/10/20 per step",
                            "parallelism": "single GPU" if world == 1 else f"users in {world} blocks (one per GPU) against the whole item table, all-reduce of the metric sums"},
                 "roofline": roofline, "roofline_exact_kernel": roofline_exact, "roofline_spmm": roofline_spmm,
+                "roofline_spmm_scaleup_slice": roofline_slice,
                 "spmm_transpose_ms": round(ms_spmm_t, 5),
                 "eval_forward_ms": round(t_fwd, 3), "epoch": epoch, "trained": trained, "cpu_baseline": cpu,
                 "recall@20": round(float(res["recall@20"]), 6),
