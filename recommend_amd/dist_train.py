@@ -410,7 +410,7 @@ class ShardedTrainStep:
         if capture is None:
             capture = (self.world == 1 and not dist.is_initialized()) or dist.get_backend(self.group) == "nccl"
         return GraphedStep(self._step, lambda: self.opt.zero_grad(set_to_none=True), example_batch, constants,
-                           warmup_steps, capture=capture)
+                           warmup_steps, capture=capture, capture_error_mode="thread_local")
 
 
 __all__ = ["ShardedGraphConstructor", "ShardedTESTModel", "ShardedTrainStep", "gather_rows"]

@@ -25,7 +25,7 @@ class GraphedStep:
 
     def __init__(self, body: Callable[[Dict], torch.Tensor], zero_grad: Callable[[], None],
                  example_batch: Dict[str, torch.Tensor], constants: Optional[Dict[str, torch.Tensor]] = None,
-                 warmup_steps: int = 3, capture: bool = True):
+                 warmup_steps: int = 3, capture: bool = True, capture_error_mode: str = "global"):
         if warmup_steps < 1:
             # optimizers create their state on the first step; created inside the capture it would
             # be re-zeroed by every replay
@@ -50,7 +50,9 @@ class GraphedStep:
             return
         self.graph = torch.cuda.CUDAGraph()
         self._zero_grad()
-        with torch.cuda.graph(self.graph, stream=s):
+        # (capture_error_mode "thread_local": other threads -- the collective backend's watchdog -- may
+        # query events while this thread records; the default forbids that for every thread)
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode=capture_error_mode):
             self.static_loss = self._body({**self.static, **self.constants})
 
     def _body(self, batch):
