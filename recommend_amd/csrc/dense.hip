@@ -27,6 +27,7 @@
 
 #include <type_traits>
 
+#include "bf16x3.h"
 #include "common.h"
 #include "dense_wide.h"
 #include "slab_reduce.h"
@@ -34,64 +35,13 @@
 namespace {
 
 using rk::kWave;
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// fp32 products on the bf16 matrix pipe.  x = h + m + l with h, m, l bf16 (8 significant bits
-// each: all 24 of an fp32 mantissa, every subtraction below exact), and
-//   x * w = hh + hm + mh + mm + hl + lh   (+ ml + lm + ll, below 2^-24 |x| |w|, dropped):
-// six v_mfma_f32_32x32x16_bf16 of 32 cycles per 16 k against eight fp32-input MFMAs of 64, and,
-// unlike those, not on the vector ALU's issue port.  Sums are fp32 inside the MFMA as before.
-template <int NV>
-struct SplitN {
-  bf16x8 h[NV / 8], m[NV / 8], l[NV / 8];   // element 8s + j is the lane's reduction index 8s + j
-};
-using Split3 = SplitN<32>;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// Two values at a time, so that every step is one packed instruction or one per value: convert
-// (v_cvt_pk_bf16_f32), widen the two halves back (shift / mask), subtract (v_pk_add_f32):
-// 9 instructions per pair.
-__device__ __forceinline__ f32x2 widen(uint32_t pk) {
-  return f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xFFFF0000u)};
-}
-template <int NV>
-__device__ __forceinline__ void split3(const float (&x)[NV], SplitN<NV> &o) {
-#pragma unroll
-  for (int s4 = 0; s4 < NV / 8; ++s4) {
-    u32x4 hh, mm, ll;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x2 v = {x[8 * s4 + 2 * q], x[8 * s4 + 2 * q + 1]};
-      const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-      const f32x2 r1 = v - widen(h);
-      const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
-      const f32x2 r2 = r1 - widen(m);
-      hh[q] = h;
-      mm[q] = m;
-      ll[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
-    }
-    o.h[s4] = __builtin_bit_cast(bf16x8, hh);
-    o.m[s4] = __builtin_bit_cast(bf16x8, mm);
-    o.l[s4] = __builtin_bit_cast(bf16x8, ll);
-  }
-}
-// acc += A (32 rows x this lane's NV reduction indices) * B^T in six bf16 products per step of 8;
-// the small terms first, the leading one last
-template <int NV>
-__device__ __forceinline__ void mfma_split3(const SplitN<NV> &a, const SplitN<NV> &b, floatx16 &acc) {
-#pragma unroll
-  for (int s4 = 0; s4 < NV / 8; ++s4) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s4], b.h[s4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.l[s4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b.m[s4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b.h[s4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.m[s4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b.h[s4], acc, 0, 0, 0);
-  }
-}
+using rk::bf16x8;
+using rk::floatx16;
+using rk::floatx4;
+using rk::mfma_split3;
+using rk::split3;
+using rk::Split3;
+using rk::SplitN;
 
 constexpr int DD = 64;        // layer width (in = out)
 constexpr int WT = 32;        // rows per wavefront tile
