@@ -229,8 +229,9 @@ int rk_dense_bwd_accum_f32(const float *X, const float *W, const float *b,
 /* The backward pass in two halves, for callers that differentiate many layers in a row (one
  * MGCN branch: 13 calls): rk_dense_bwd_partials_f32 is rk_dense_bwd_f32 without its closing
  * reduction -- it leaves *n_part_out_host per-workgroup partial sums of dW / db / dalpha in `slab`
- * (rk_dense_bwd_slab_bytes; K = D = 64 only) -- and rk_dense_reduce_jobs_f32 then reduces any
- * number of slabs in one launch.  A job lists the slabs whose sums go, added in list order,
+ * (rk_dense_bwd_slab_bytes; 0 for widths without the two-half form) -- and
+ * rk_dense_reduce_jobs_d_f32 (rk_dense_reduce_jobs_f32 for D = 64) then reduces any number of slabs of
+ * layers of width D in one launch.  A job lists the slabs whose sums go, added in list order,
  * to one set of outputs (one slab per application of that weight): the results are bit for
  * bit those of rk_dense_bwd_f32 / rk_dense_bwd_accum_f32 called layer by layer.  db and dalpha
  * may be NULL.  jobs_host is a HOST array. */
@@ -250,6 +251,8 @@ int rk_dense_bwd_partials_f32(const float *X, const float *W, const float *b,
                               int32_t *n_part_out_host, void *stream);
 int rk_dense_reduce_jobs_f32(const rk_dense_reduce_job *jobs_host, int32_t n_jobs,
                              void *stream);
+int rk_dense_reduce_jobs_d_f32(const rk_dense_reduce_job *jobs_host, int32_t n_jobs,
+                               int32_t D, void *stream);
 
 /* ---- W2: modality-weighted sum (device) ---------------------------------- */
 /* Replaces torch.sum(torch.stack(modal_features) * softmax(alphas)[:, None, None], 0),

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rk_dense_bwd_partials_f32": (c_int32, [P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32, c_int32,
                                             P, P, c_size_t, POINTER(c_int32), P]),
     "rk_dense_reduce_jobs_f32": (c_int32, [P, c_int32, P]),
+    "rk_dense_reduce_jobs_d_f32": (c_int32, [P, c_int32, c_int32, P]),
     "rk_modal_sum_fwd_f32": (c_int32, [P, c_int32, P, c_int64, P, P]),
     "rk_modal_sum_bwd_ws_bytes": (c_size_t, []),
     "rk_modal_sum_bwd_f32": (c_int32, [P, P, c_int32, P, P, c_int64, P, P, c_size_t, P]),

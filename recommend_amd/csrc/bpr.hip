@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void bpr_bwd_kernel(
 // leaves (that one owns the row), otherwise it accumulates every match as the scan passes it.  No
 // atomics, no sorting, no scratch; n^2 / 16 compare steps of a lane group for n contributions
 // (n = 512 at the Elec preset: 32 steps per group), which is why rk_rank_loss_bwd_f32 switches to
-// the atomic kernel above kDetMaxContrib contributions.
+// the atomic kernel above kDetMaxContrib contributions.  Up to kLdsKeys contributions every
+// workgroup first copies the keys to LDS and scans them there (the scan is a chain of dependent
+// key loads: out of L2 it was 95 us for 2048 contributions, the Clothing preset's batch).
 constexpr int64_t kDetMaxContrib = 32768;
+constexpr int kLdsKeys = 4096;   // 32 KB of int64 keys
 constexpr int kMaxQ = 4;   // float4 per lane and pass: rows up to 256 floats in one pass, wider rows in several
 
 // d loss / d x of negative r of one sample (x_row / mask_row: the sample's R saved values), as in
@@ -225,7 +228,7 @@ __device__ __forceinline__ float bwd_coef(const float *__restrict__ x_row, const
   return mode == kModeSoftmaxCE ? -scale * expf(xv) : -scale * m / (1.0f + expf(xv));
 }
 
-template <bool ITEMS>
+template <bool ITEMS, bool LDS_KEYS>
 __global__ __launch_bounds__(256) void bpr_bwd_det_kernel(
     const float *__restrict__ U, const float *__restrict__ I, int32_t D,
     const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
@@ -233,11 +236,17 @@ __global__ __launch_bounds__(256) void bpr_bwd_det_kernel(
     const float *__restrict__ mask, const float *__restrict__ x,
     const float *__restrict__ loss_out, const float *__restrict__ gout, int mode,
     float *__restrict__ dst) {
+  __shared__ int64_t keys[LDS_KEYS ? kLdsKeys : 1];
   const int sub = threadIdx.x % GL;
   const int64_t n = ITEMS ? B * (1 + R) : B;
   const int64_t c = (int64_t)blockIdx.x * SPB + threadIdx.x / GL;
+  auto gkey = [&](int64_t i) -> int64_t { return !ITEMS ? users[i] : (i < B ? pos[i] : neg[i - B]); };
+  if constexpr (LDS_KEYS) {
+    for (int64_t i = threadIdx.x; i < n; i += 256) keys[i] = gkey(i);
+    __syncthreads();
+  }
   if (c >= n) return;                       // whole lane groups leave; nothing below synchronises wider
-  auto key = [&](int64_t i) -> int64_t { return !ITEMS ? users[i] : (i < B ? pos[i] : neg[i - B]); };
+  auto key = [&](int64_t i) -> int64_t { return LDS_KEYS ? keys[LDS_KEYS ? i : 0] : gkey(i); };
   const int64_t my = key(c);
   const int d4 = D / 4;
   const float scale = gout[0] / loss_out[1];
@@ -498,11 +507,20 @@ int rk_rank_loss_bwd_f32(const float *U, const float *I, int32_t D,
     RK_CHECK_LAUNCH("bpr_bwd_kernel");
     return RK_OK;
   }
-  bpr_bwd_det_kernel<false><<<(int32_t)rk::ceil_div(B, SPB), 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask, x,
-                                                                          loss_out, gout, mode, dU);
+  const int64_t n_items_side = B * (1 + (int64_t)R);
+  if (B <= kLdsKeys)
+    bpr_bwd_det_kernel<false, true><<<(int32_t)rk::ceil_div(B, SPB), 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask,
+                                                                                  x, loss_out, gout, mode, dU);
+  else
+    bpr_bwd_det_kernel<false, false><<<(int32_t)rk::ceil_div(B, SPB), 256, 0, st>>>(U, I, D, users, pos, neg, B, R, mask,
+                                                                                   x, loss_out, gout, mode, dU);
   RK_CHECK_LAUNCH("bpr_bwd_det_kernel<users>");
-  bpr_bwd_det_kernel<true><<<(int32_t)rk::ceil_div(B * (1 + (int64_t)R), SPB), 256, 0, st>>>(
-      U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dI);
+  if (n_items_side <= kLdsKeys)
+    bpr_bwd_det_kernel<true, true><<<(int32_t)rk::ceil_div(n_items_side, SPB), 256, 0, st>>>(
+        U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dI);
+  else
+    bpr_bwd_det_kernel<true, false><<<(int32_t)rk::ceil_div(n_items_side, SPB), 256, 0, st>>>(
+        U, I, D, users, pos, neg, B, R, mask, x, loss_out, gout, mode, dI);
   RK_CHECK_LAUNCH("bpr_bwd_det_kernel<items>");
   return RK_OK;
 }

@@ -802,6 +802,7 @@ int rk_dense_bwd_f32(const float *X, const float *W, const float *b, const float
 }
 
 size_t rk_dense_bwd_slab_bytes(int64_t n_rows, int32_t K, int32_t D) {
+  if (n_rows > 0 && K == 128 && D == 128) return rk::dense128_slab_bytes();
   if (n_rows <= 0 || K != DD || D != DD) return 0;
   return (size_t)kBwdMaxGrid * PART * sizeof(float);
 }
@@ -810,14 +811,16 @@ int rk_dense_bwd_partials_f32(const float *X, const float *W, const float *b, co
                               uint64_t seed, const uint64_t *seed_step, const float *G, int64_t n_rows, int32_t K,
                               int32_t D, float *dX, float *slab, size_t slab_bytes, int32_t *n_part_out, void *stream) {
   RK_CHECK_ARG(n_rows > 0, "empty layer input");
-  if (K != DD || D != DD)
-    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_partials_f32: built for 64 -> 64 layers (got %d -> %d)", K, D);
+  if (K != D || (D != DD && D != 128))
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_bwd_partials_f32: built for 64 -> 64 and 128 -> 128 layers (got %d -> %d)", K, D);
   RK_CHECK_ARG(X && W && G && slab && n_part_out, "null pointer");
   RK_CHECK_ARG(p_drop >= 0.0f && p_drop < 1.0f, "dropout probability must be in [0, 1)");
   RK_CHECK_ARG(slab_bytes >= rk_dense_bwd_slab_bytes(n_rows, K, D), "slab too small");
   RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(G) && rk::aligned16(dX) && rk::aligned16(slab),
                "matrices must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (D == 128)
+    return rk::dense128_bwd_partials(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, slab, n_part_out, st);
   const int grid = bwd_grid(n_rows);
   if (alpha)
     dense_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, slab);
@@ -829,13 +832,20 @@ int rk_dense_bwd_partials_f32(const float *X, const float *W, const float *b, co
 }
 
 int rk_dense_reduce_jobs_f32(const rk_dense_reduce_job *jobs, int32_t n_jobs, void *stream) {
+  return rk_dense_reduce_jobs_d_f32(jobs, n_jobs, DD, stream);
+}
+
+int rk_dense_reduce_jobs_d_f32(const rk_dense_reduce_job *jobs, int32_t n_jobs, int32_t D, void *stream) {
   RK_CHECK_ARG(n_jobs >= 0 && (jobs || n_jobs == 0), "bad job list");
+  if (D != DD && D != 128)
+    return rk::fail(RK_ERR_UNSUPPORTED, "rk_dense_reduce_jobs_d_f32: built for layer widths 64 and 128 (got %d)", D);
   for (int32_t j = 0; j < n_jobs; ++j) {
     RK_CHECK_ARG(jobs[j].n_slabs >= 1 && jobs[j].n_slabs <= RK_DENSE_REDUCE_MAX_SLABS, "a job lists 1..RK_DENSE_REDUCE_MAX_SLABS slabs");
     RK_CHECK_ARG(jobs[j].n_part >= 1 && jobs[j].n_part <= kBwdMaxGrid && jobs[j].dW, "bad job");
     for (int32_t sl = 0; sl < jobs[j].n_slabs; ++sl) RK_CHECK_ARG(jobs[j].slabs[sl], "null slab");
   }
   hipStream_t st = (hipStream_t)stream;
+  if (D == 128) return rk::dense128_reduce_jobs(jobs, n_jobs, st);
   for (int32_t j0 = 0; j0 < n_jobs; j0 += kJobsPerLaunch) {
     const int32_t nj = std::min<int32_t>(kJobsPerLaunch, n_jobs - j0);
     ReduceJobs args;

@@ -28,6 +28,8 @@
 // fragments in registers); dW[n][k] += sum_rows dZ[row][n] X[row][k] (wavefront w: n = 32w..32w+31,
 // all four k tiles; the accumulators live in registers across the launch); db, d(alpha) likewise.
 // Per-workgroup partials are added in workgroup order by a second launch: no float atomics.
+#include <string.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -578,6 +580,49 @@ __global__ __launch_bounds__(256) void dense128_reduce_kernel(const float *__res
     dalpha[0] = accumulate ? dalpha[0] + s : s;
 }
 
+// The same reduction for several layers in one launch (blockIdx.y = job), as dense.hip's
+// dense_reduce_jobs_kernel: a job that lists several slabs adds their sums in list order, with the
+// operations the accumulate form of the kernel above would have performed call by call.
+constexpr int kJobsPerLaunchW = 16;
+struct ReduceJobsW {
+  rk_dense_reduce_job job[kJobsPerLaunchW];
+};
+__global__ __launch_bounds__(256) void dense128_reduce_jobs_kernel(ReduceJobsW jobs) {
+  __shared__ float red[16][17];
+  const rk_dense_reduce_job &jb = jobs.job[blockIdx.y];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + el;
+  float total = 0.0f;
+  for (int32_t sl = 0; sl < jb.n_slabs; ++sl) {      // uniform over the workgroup
+    const float *__restrict__ slab = jb.slabs[sl];
+    float s0 = 0.0f, s1 = 0.0f;
+    if (idx < NREDW) {
+      int32_t p = q;
+      for (; p + 16 < jb.n_part; p += 32) {
+        s0 += slab[(int64_t)p * PARTW + idx];
+        s1 += slab[(int64_t)(p + 16) * PARTW + idx];
+      }
+      if (p < jb.n_part) s0 += slab[(int64_t)p * PARTW + idx];
+    }
+    __syncthreads();                                 // the previous slab's fold has been read
+    red[q][el] = s0 + s1;
+    __syncthreads();
+    if (q == 0) {
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[k][el];
+      total = sl == 0 ? s : total + s;
+    }
+  }
+  if (q != 0 || idx >= NREDW) return;
+  if (idx < DW * DW)
+    jb.dW[idx] = total;
+  else if (idx < DW * DW + DW) {
+    if (jb.db) jb.db[idx - DW * DW] = total;
+  } else if (jb.dalpha)
+    jb.dalpha[0] = total;
+}
+
 constexpr int kMaxGrid = 512;
 inline int grid_for(int64_t n_rows, int wg_per_cu = 1) {
   int dev = 0, cus = 256;
@@ -615,6 +660,32 @@ int dense128_fwd(const float *X1, const float *W1, const float *X2, const float 
 }
 
 size_t dense128_bwd_ws_bytes() { return (size_t)kMaxGrid * PARTW * sizeof(float); }
+size_t dense128_slab_bytes() { return (size_t)kMaxGrid * PARTW * sizeof(float); }
+
+int dense128_bwd_partials(const float *X, const float *W, const float *b, const float *alpha, float p_drop, uint64_t seed,
+                          const uint64_t *seed_step, const float *G, int64_t n_rows, float *dX, float *slab,
+                          int32_t *n_part_out, hipStream_t st) {
+  const int grid = grid_for(n_rows);
+  if (alpha)
+    dense128_bwd_kernel<true><<<grid, 256, 0, st>>>(X, W, b, alpha, p_drop, seed, seed_step, G, n_rows, dX, slab);
+  else
+    dense128_bwd_kernel<false><<<grid, 256, 0, st>>>(X, W, b, nullptr, p_drop, seed, seed_step, G, n_rows, dX, slab);
+  RK_CHECK_LAUNCH("dense128_bwd_kernel");
+  *n_part_out = grid;
+  return RK_OK;
+}
+
+int dense128_reduce_jobs(const rk_dense_reduce_job *jobs, int32_t n_jobs, hipStream_t st) {
+  for (int32_t j0 = 0; j0 < n_jobs; j0 += kJobsPerLaunchW) {
+    const int32_t nj = std::min<int32_t>(kJobsPerLaunchW, n_jobs - j0);
+    ReduceJobsW args;
+    memset(&args, 0, sizeof args);
+    for (int32_t j = 0; j < nj; ++j) args.job[j] = jobs[j0 + j];
+    dense128_reduce_jobs_kernel<<<dim3((NREDW + 15) / 16, nj), 256, 0, st>>>(args);
+    RK_CHECK_LAUNCH("dense128_reduce_jobs_kernel");
+  }
+  return RK_OK;
+}
 
 int dense128_bwd(const float *X, const float *W, const float *b, const float *alpha, float p_drop, uint64_t seed,
                  const uint64_t *seed_step, const float *G, int64_t n_rows, float *dX, float *dW, float *db,

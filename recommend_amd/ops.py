@@ -464,7 +464,7 @@ class DenseReduceQueue:
     A call with `defer=queue` leaves its per-workgroup partial sums in a slab of its own and
     returns dW / db / dalpha tensors that hold their values only after flush(); calls that add to
     the same tensors (grads=...) become one job whose slabs are summed in call order -- the bits
-    are those of the immediate calls.  Built for the 64-wide layers; other widths reduce at once."""
+    are those of the immediate calls.  Built for the 64- and 128-wide layers."""
 
     def __init__(self, n_rows, width, device):
         self.n_rows, self.width, self.device = int(n_rows), int(width), device
@@ -501,7 +501,7 @@ class DenseReduceQueue:
             arr[j].dW = dw.data_ptr()
             arr[j].db = db.data_ptr() if db is not None else None
             arr[j].dalpha = da.data_ptr() if da is not None else None
-        _ffi.call("rk_dense_reduce_jobs_f32", arr, c_int32(len(self.jobs)), stream_ptr(self.device))
+        _ffi.call("rk_dense_reduce_jobs_d_f32", arr, c_int32(len(self.jobs)), c_int32(self.width), stream_ptr(self.device))
         self.jobs = []
 
 

@@ -182,13 +182,13 @@ def test_dense_products_keep_fp32_accuracy_over_the_exponent_range():
     assert float(((wd.grad.cpu().double() - g6.T @ x6).abs() / bound_dw).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("n", [5000, 70001])
-def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(n):
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(n, D):
     """ops.DenseReduceQueue: the closing reductions of several layer backward calls as one launch,
     among them one weight applied three times (its slabs are added in call order).  Every output
     bit for bit what the calls produce when each reduces at once."""
     g = torch.Generator().manual_seed(n)
-    D = 64
     xs = [torch.randn(n, D, generator=g).to(DEV) for _ in range(5)]
     gs = [torch.randn(n, D, generator=g).to(DEV) for _ in range(5)]
     ws_ = [(torch.randn(D, D, generator=g) * 0.2).to(DEV) for _ in range(3)]
@@ -222,5 +222,5 @@ def test_deferred_weight_gradient_reductions_equal_the_immediate_ones(n):
     for a, e in zip(got, want):
         assert torch.equal(a, e)
     # a width the deferred form is not built for reduces at once
-    q128 = ops.DenseReduceQueue(1000, 128, torch.device(DEV))
-    assert not q128.usable
+    q256 = ops.DenseReduceQueue(1000, 256, torch.device(DEV))
+    assert not q256.usable
