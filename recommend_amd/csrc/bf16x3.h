@@ -64,6 +64,29 @@ __device__ __forceinline__ void mfma_split3(const SplitN<NV> &a, const SplitN<NV
   }
 }
 
+// Two independent products that share one operand, their MFMAs issued alternately: an MFMA that
+// accumulates onto the result of the one just before it waits for that result (half the issue
+// rate of the matrix pipe for a single chain).  Each accumulator sees the same operations in the
+// same order as with mfma_split3: the results are the same bits.
+template <int NV>
+__device__ __forceinline__ void mfma_split3_shared_a(const SplitN<NV> &a, const SplitN<NV> &b0, const SplitN<NV> &b1,
+                                                     floatx16 &acc0, floatx16 &acc1) {
+#pragma unroll
+  for (int s4 = 0; s4 < NV / 8; ++s4) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s4], b0.h[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s4], b1.h[s4], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b0.l[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b1.l[s4], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b0.m[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b1.m[s4], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b0.h[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s4], b1.h[s4], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b0.m[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b1.m[s4], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b0.h[s4], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b1.h[s4], acc1, 0, 0, 0);
+  }
+}
 // the same split for four values that leave as three 8-byte packs (h, m, l of x, y, z, w)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_quad(float x, float y, float z, float w, u32x2 &h, u32x2 &m, u32x2 &l) {

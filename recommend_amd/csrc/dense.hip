@@ -271,15 +271,13 @@ __global__ __launch_bounds__(256, (DUAL || HAS_R) ? 1 : 2) void dense_fwd_kernel
     // the DMA of the tile after next, which has two tiles' MFMAs and epilogues to land.
     Split3 as;
     split3(a, as);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) mfma_split3(as, w1[t], acc[t]);
+    rk::mfma_split3_shared_a(as, w1[0], w1[1], acc[0], acc[1]);   // the two column blocks' chains, alternately
     if constexpr (DUAL) {
       load_row_frag(xb, frag_off, a);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       if (next < n_tiles) stage_rows(X2, next * WT, n_rows, xb, lane_off);
       split3(a, as);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) mfma_split3(as, w2[DUAL ? t : 0], acc[t]);
+      rk::mfma_split3_shared_a(as, w2[0], w2[DUAL ? 1 : 0], acc[0], acc[1]);
     }
 
     // Epilogue in accumulator layout: lane = column 32t + col, registers = rows.  Compiled four
