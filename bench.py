@@ -618,37 +618,41 @@ def main():
                 return {"user_ids": torch.from_numpy(tu[sel]).to(dev), "item_ids": torch.from_numpy(ti[sel]).to(dev),
                         "neg_items": torch.from_numpy(gen.integers(0, I, (Bg, 1))).to(dev)}
             batches = [global_batch() for _ in range(8)]
-            # the step, collectives included, as one captured HIP graph per rank (RCCL only; the gloo
-            # rehearsal runs it eagerly); BENCH_SHARDED_EAGER=1 times the eager form on RCCL as well
-            captured = backend == "nccl" and os.environ.get("BENCH_SHARDED_EAGER") != "1"
-            capture_error = None
-            try:
-                sstep = sstep.graphed(batches[0], warmup_steps=3, capture=captured)
-            except Exception as e:      # the recording failed (on every rank alike): time the eager step instead
-                if not captured:
-                    raise
-                capture_error, captured = repr(e), False
-                torch.cuda.synchronize()
-                sstep = ShardedTrainStep(smodel, sopt, gather_dot_bpr_loss, max_grad_norm=1.0)
-            for b in batches[:2]:
-                sstep(b)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
             n_timed = 10
-            for i in range(n_timed):
-                last = sstep(batches[i % len(batches)])
-            torch.cuda.synchronize()
-            dist.barrier()
-            t = torch.tensor([(time.perf_counter() - t0) / n_timed * 1e3], dtype=torch.float64, device=dev)
-            all_reduce_tensor(t, dist.ReduceOp.MAX)
-            sharded_train = {"ms_per_train_step": round(float(t), 4), "global_batch": Bg, "steps_timed": n_timed,
-                             "last_loss": round(float(last), 6),
-                             "captured_graph": bool(captured), "capture_error": capture_error,
-                             "layout": f"rows of the graph and of every node matrix over {world} ranks, batch split; "
-                                       "clip + Adam by the library's kernel pair; "
-                                       + ("one captured HIP graph per rank, RCCL collectives inside" if captured
-                                          else "eager launches")}
+
+            def time_steps(run):
+                for bt in batches[:2]:
+                    run(bt)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for i in range(n_timed):
+                    last = run(batches[i % len(batches)])
+                torch.cuda.synchronize()
+                dist.barrier()
+                t = torch.tensor([(time.perf_counter() - t0) / n_timed * 1e3], dtype=torch.float64, device=dev)
+                all_reduce_tensor(t, dist.ReduceOp.MAX)
+                return round(float(t), 4), round(float(last), 6)
+
+            layout = (f"rows of the graph and of every node matrix over {world} ranks, batch split; "
+                      "clip + Adam by the library's kernel pair; ")
+            # First the eager form, so that the line holds a measured step even if recording the graph
+            # (the first time RCCL collectives of several ranks are captured on this machine) never returns.
+            ms, last = time_steps(sstep)
+            sharded_train = {"ms_per_train_step": ms, "ms_per_train_step_eager": ms, "global_batch": Bg, "steps_timed": n_timed,
+                             "last_loss": last, "captured_graph": False, "capture_error": None,
+                             "layout": layout + "eager launches"}
+            # Then the step, collectives included, as one captured HIP graph per rank (RCCL only; the gloo
+            # rehearsal has no capturable collectives); BENCH_SHARDED_EAGER=1 skips it.
+            if backend == "nccl" and os.environ.get("BENCH_SHARDED_EAGER") != "1":
+                try:
+                    gstep = sstep.graphed(batches[0], warmup_steps=3, capture=True)
+                    ms, last = time_steps(gstep)
+                    sharded_train.update({"ms_per_train_step": ms, "last_loss": last, "captured_graph": True,
+                                          "layout": layout + "one captured HIP graph per rank, RCCL collectives inside"})
+                except Exception as e:      # the recording failed (on every rank alike): the eager numbers stand
+                    sharded_train["capture_error"] = repr(e)
+                    torch.cuda.synchronize()
         except Exception as e:
             sharded_train = {"error": repr(e)}
     if watchdog is not None:
