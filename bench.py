@@ -200,20 +200,36 @@ def launch_ranks(n, backend):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     limit = float(os.environ.get("BENCH_JOB_LIMIT_S", "1500"))
-    t0, worst = time.time(), 0
+    t0, worst, grace_end = time.time(), 0, None
     try:
-        out, _ = procs[0].communicate(timeout=limit)
-        sys.stdout.write(out.decode())
-        sys.stdout.flush()
-        for p in procs:
-            worst = max(worst, abs(p.wait(timeout=max(1.0, limit - (time.time() - t0)))))
-    except subprocess.TimeoutExpired:
-        print(f"[bench] the {n}-rank job did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
-        worst = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            now = time.time()
+            if grace_end is None and any(c not in (None, 0) for c in codes):
+                # a rank has failed: the others sit in a collective that will never complete
+                grace_end = now + float(os.environ.get("BENCH_FAIL_GRACE_S", "60"))
+                bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+                print(f"[bench] rank(s) {bad} exited with {[codes[i] for i in bad]}; ending the job", file=sys.stderr, flush=True)
+            if now - t0 > limit or (grace_end is not None and now > grace_end):
+                if grace_end is None:
+                    print(f"[bench] the {n}-rank job did not finish within {limit:.0f} s", file=sys.stderr, flush=True)
+                worst = 124
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:           # the exact processes started above, nothing else
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+    # whatever rank 0 has printed (its one line fits the pipe's buffer, so it never blocked on it)
+    sys.stdout.write(procs[0].stdout.read().decode())
+    sys.stdout.flush()
+    for p in procs:
+        if worst != 124 or p.returncode not in (None, -9):     # our own kill is not a rank's failure
+            worst = max(worst, abs(p.returncode or 0))
     return worst
 
 
