@@ -33,9 +33,11 @@ for world in WORLDS:
     pt, ct = torch.from_numpy(p).cuda(), torch.from_numpy(c).cuda()
     blk = ue[:hi].contiguous()
     row = [f"world {world}: {hi:6d} users/rank"]
-    for mode in ("exact", "filter", "auto"):
+    for mode in os.environ.get("PROBE_MODES", "exact,filter,auto").split(","):
         ms = t(lambda: ops.score_topk(blk, ie, 20, pt, ct, mode=mode))
         row.append(f"{mode} {ms:.3f} ms")
-    base = base or ms
-    row.append(f"ideal {base / world:.3f} ms")
+    if world == 1:
+        base = ms
+    if base is not None:
+        row.append(f"ideal {base / world:.3f} ms")
     print("  ".join(row), flush=True)
