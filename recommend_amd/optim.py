@@ -135,15 +135,28 @@ class FusedClipAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
-        """Moments and step count of a checkpoint (this optimizer's or torch.optim.Adam's).  The
-        descriptor tables of earlier steps point at the moments they were built for: dropped."""
+        """Moments and step count of a checkpoint (this optimizer's or torch.optim.Adam's).  Moment
+        buffers that exist already keep their memory and take the checkpoint's VALUES, so a training
+        step recorded in a HIP graph before the load (its kernels hold the buffers' addresses) goes on
+        updating the moments the optimizer reports; the learning rate of the checkpoint reaches the
+        device scalar at once for the same reason.  Call it outside graph capture."""
+        old = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items() if "exp_avg" in st}
         super().load_state_dict(state_dict)
-        self._tables = {}
+        for q, (m, v) in old.items():
+            st = self.state.get(q)
+            if st is None or "exp_avg" not in st:
+                continue
+            if st["exp_avg"].shape == m.shape and st["exp_avg"].device == m.device:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+        self._tables = {}        # descriptor tables are rebuilt from the state at the next step
         steps = [float(st["step"]) for st in self.state.values() if "step" in st]
         self._restored_step = int(max(steps)) if steps else 0
         if self._dev is not None:
             self.step_count.fill_(self._restored_step)
         self._lr_host = None
+        self.sync_lr()
 
     def sync_lr(self):
         """Push a learning rate changed by a scheduler to the device scalar (call outside graph capture)."""

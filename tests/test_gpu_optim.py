@@ -85,7 +85,12 @@ def test_checkpoint_round_trip_continues_like_torch_adam():
     sd_t = copy.deepcopy(topt.state_dict())        # torch's own checkpoint, step 7
     for p, q in zip(ours, ref):
         p.data.copy_(q.data)
+    where = [opt.state[p]["exp_avg"].data_ptr() for p in ours]
     opt.load_state_dict(sd_t)
+    # the moments took the checkpoint's values in place: a step recorded in a HIP graph earlier holds these addresses
+    assert where == [opt.state[p]["exp_avg"].data_ptr() for p in ours]
+    for p, q in zip(ours, ref):
+        assert torch.equal(opt.state[p]["exp_avg"], topt.state[q]["exp_avg"])
     for _ in range(2):
         both_step(opt, ours)
     assert int(opt.step_count) == 9
