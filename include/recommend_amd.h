@@ -194,8 +194,7 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
  * replayed from a captured HIP graph draws a new mask every step; forward and
  * backward of one layer must see the same seed and the same counter value.
  * W: D x K (nn.Linear layout).  Built for K = D = 64 and K = D = 128.
- * Arithmetic at D = 128: fp32-input MFMA, an fp32 fma chain per output element.
- * Arithmetic at D = 64: every fp32 operand is split into three bf16 parts and the six
+ * Arithmetic (both widths): every fp32 operand is split into three bf16 parts and the six
  * leading partial products are summed in fp32 on the bf16 matrix pipe: the error
  * of a product is that of an fp32 dot product (<= 1e-6 of sum |x_k w_k|); operands
  * beyond bf16's largest finite value (3.39e38) yield NaN. */
@@ -441,7 +440,7 @@ int rk_bpr_scores_bwd_f32(const float *x, const float *mask,
  * Ranking: score descending, ties by lower item id.  mask_ptr/mask_items: CSR of
  * the training interactions per user (items ascending, local to this item
  * range), may be NULL.  Item ids written are local index + item_id_offset.
- * out_scores/out_ids: n_users x K, sorted.  1 <= K <= min(n_items, 128).  K <= 32 is one
+ * out_scores/out_ids: n_users x K, sorted.  1 <= K <= n_items (evalue/metric.py:9-10).  K <= 32 is one
  * per-lane list; a longer ranking (D = 64 or 128 only) is produced 32 places at a time by the
  * exact kernel, every page restricted to the items that rank strictly after the last entry
  * of the page before (one pass over the items per page).
@@ -506,7 +505,7 @@ int rk_topk_merge_f32(const float *scores, const int32_t *ids, int32_t n_users,
 /* Replaces torch.topk(scores, k, dim=1, largest=True, sorted=True) of
  * evaluate_all_at_k, evalue/metric.py:114, for callers that hand over the dense
  * scores[n_rows, n_items] (row stride ld floats).  Ranking: score descending, ties by
- * lower column id.  out_scores/out_ids: n_rows x K.  1 <= K <= min(n_items, 128) (above 32: pages
+ * lower column id.  out_scores/out_ids: n_rows x K.  1 <= K <= n_items (above 32: pages
  * of 32 places, one scan of the scores per page). */
 size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K);
 int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items,
@@ -532,7 +531,8 @@ int rk_score_topk_wide_f32(const float *A, int32_t n_a, const float *B,
 /* Replaces evaluate_all_at_k, evalue/metric.py:106-164, for every k in k_list
  * at once from one sorted top-Kmax id list per user and the CSR of the target
  * (validation/test) items per user (sorted).  discounts[j] = 1/log2(j+2).  Up to 8 values of k,
- * each in [1, min(128, id_stride)].
+ * each in [1, id_stride] (up to 128 the ranked ids of a user sit in registers; longer rankings are
+ * walked from memory, one place after the other).
  * out[ki*6 + m], m = precision, recall, hit_rate, ndcg, map, mrr: means over
  * all n_users rows.  sums_out (may be NULL): the same as double sums before
  * the division (for cross-GPU reduction).  ws: rk_rank_metrics_ws_bytes(). */

@@ -280,12 +280,13 @@ __global__ __launch_bounds__(64) void topk_merge_heads_kernel(
   }
 }
 
-// Rankings longer than one list (32 < K <= kMaxK) are produced a page of kPage places at a time:
+// Rankings longer than one list (K > 32, up to the number of items) are produced a page of kPage places at a time:
 // page p is the kPage best among the items that rank strictly after the last entry of page p - 1.
 // This kernel files a finished page (n_rows x kPage, local ids) under columns col0.. of the
 // K-wide outputs and records every row's last entry as the ceiling of the next page (a page
 // that is not full has exhausted its row: nothing ranks after (-inf, INT32_MAX)).
-constexpr int kPage = 32, kMaxK = 128;
+constexpr int kPage = 32;
+constexpr int kMaxK = 128;   // longest ranking whose ids the metrics kernel holds in registers (longer: rank_metrics_stream_kernel)
 __global__ __launch_bounds__(256) void place_page_kernel(const float *__restrict__ page_s, const int32_t *__restrict__ page_id,
                                                          int32_t n_rows, int32_t K, int32_t col0, int32_t id_offset,
                                                          float *__restrict__ out_s, int32_t *__restrict__ out_id,
@@ -438,6 +439,75 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(
 #pragma unroll
   for (int i = 0; i < MAXK * 6; ++i) {
     if (i >= nk * 6) {                 // (uniform; a 64-bit shuffle reduction is 12 LDS-pipe instructions)
+      if (lane == 0) red[wave][i] = 0.0;
+      continue;
+    }
+    double v = (double)vals[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < MAXK * 6)
+    part[(int64_t)blockIdx.x * (MAXK * 6) + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// Rankings longer than kMaxK places: the ranked ids stay in memory and a lane walks its user's
+// ranking once, bisecting the (sorted) target list per place.  The sums run over the places in
+// ascending order, the same operations in the same order as in the kernel above, and a k's metrics
+// are read off when its last place has been added: the same values, at the speed of one dependent
+// chain per user (rankings this long are rare: evalue/metric.py:9-10 allows any k <= num_items).
+__global__ __launch_bounds__(256) void rank_metrics_stream_kernel(
+    const int32_t *__restrict__ topk_ids, int32_t n_users, int32_t id_stride,
+    const int32_t *__restrict__ tgt_ptr, const int32_t *__restrict__ tgt_items,
+    KList kl, int32_t nk, int32_t kmax, const float *__restrict__ disc,
+    double *__restrict__ part) {
+  __shared__ double red[4][MAXK * 6];
+  const int32_t u = blockIdx.x * 256 + threadIdx.x;
+  float vals[MAXK * 6];
+#pragma unroll
+  for (int i = 0; i < MAXK * 6; ++i) vals[i] = 0.0f;
+  if (u < n_users) {
+    const int32_t tb = tgt_ptr[u], te = tgt_ptr[u + 1];
+    const int32_t n_pos = te - tb;
+    const float positives = (float)max(n_pos, 1);
+    float hits = 0.f, dcg = 0.f, idcg = 0.f, ap = 0.f, cum = 0.f;
+    int first = 0;
+    for (int32_t j = 0; j < kmax; ++j) {
+      const int32_t it = topk_ids[(int64_t)u * id_stride + j];
+      int32_t lo = tb, hi = te;
+      while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (tgt_items[mid] < it)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const float rj = (it >= 0 && lo < te && tgt_items[lo] == it) ? 1.f : 0.f;
+      hits += rj;
+      dcg += rj * disc[j];
+      if (j < n_pos) idcg += disc[j];      // (for a k: the places below min(n_pos, k))
+      cum += rj;
+      ap += (cum / (float)(j + 1)) * rj;
+      if (rj != 0.f && first == 0) first = j + 1;
+#pragma unroll
+      for (int ki = 0; ki < MAXK; ++ki) {
+        if (ki < nk && kl.k[ki] == j + 1) {
+          vals[ki * 6 + 0] = hits / (float)(j + 1);
+          vals[ki * 6 + 1] = hits / positives;
+          vals[ki * 6 + 2] = hits > 0.f ? 1.f : 0.f;
+          vals[ki * 6 + 3] = idcg > 0.f ? dcg / idcg : 0.f;
+          vals[ki * 6 + 4] = ap / positives;
+          vals[ki * 6 + 5] = first > 0 ? 1.0f / (float)first : 0.f;
+        }
+      }
+    }
+  }
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+#pragma unroll
+  for (int i = 0; i < MAXK * 6; ++i) {
+    if (i >= nk * 6) {
       if (lane == 0) red[wave][i] = 0.0;
       continue;
     }
@@ -727,7 +797,6 @@ int check_topk_args(const float *Uemb, int32_t n_users, const float *Iemb, int32
   RK_CHECK_ARG(n_users > 0 && n_items > 0, "empty score matrix");
   // evalue/metric.py:9-10
   RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
-  if (K > kMaxK) return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above the built maximum %d", K, kMaxK);
   if (K > kPage && D != 64 && D != 128)
     return rk::fail(RK_ERR_UNSUPPORTED, "rk_score_topk_f32: K=%d above %d is built for embedding widths 64 and 128 (got %d)", K,
                     kPage, D);
@@ -745,14 +814,14 @@ int check_topk_args(const float *Uemb, int32_t n_users, const float *Iemb, int32
 extern "C" {
 
 size_t rk_score_topk_ws_bytes(int32_t n_users, int32_t n_items, int32_t D, int32_t K) {
-  if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > kMaxK) return 0;
+  if (n_users <= 0 || n_items <= 0 || D <= 0 || K <= 0 || K > n_items) return 0;
   return topk_workspace(n_users, n_items, D, K).total;
 }
 
 int rk_score_topk_open_users(int32_t n_users, int32_t n_items, int32_t D, int32_t K, const void *ws,
                              size_t ws_bytes, void *stream, int32_t *open_users) {
   RK_CHECK_ARG(ws && open_users, "null pointer");
-  RK_CHECK_ARG(n_users > 0 && n_items > 0 && D > 0 && K >= 1 && K <= kMaxK, "bad sizes");
+  RK_CHECK_ARG(n_users > 0 && n_items > 0 && D > 0 && K >= 1 && K <= n_items, "bad sizes");
   *open_users = 0;
   if (filter_len(K) == 0 || (D != 64 && D != 128)) return RK_OK;
   const TopkWorkspace w = topk_workspace(n_users, n_items, D, K);
@@ -887,7 +956,7 @@ int rk_score_topk_filtered_f32(const float *Uemb, int32_t n_users, const float *
 }
 
 size_t rk_rows_topk_ws_bytes(int32_t n_rows, int32_t K) {
-  if (n_rows <= 0 || K <= 0 || K > kMaxK) return 0;
+  if (n_rows <= 0 || K <= 0) return 0;
   const size_t lists = (size_t)n_rows * ROWS_LANES * kpad_for(std::min(K, kPage)) * (sizeof(float) + sizeof(int32_t));
   if (K <= kPage) return lists;
   // paged: one finished page and the rows' ceilings behind the partial lists
@@ -899,7 +968,6 @@ int rk_rows_topk_f32(const float *scores, int32_t n_rows, int32_t n_items, int64
   RK_CHECK_ARG(n_rows >= 0 && n_items > 0 && ld >= n_items, "bad score matrix shape");
   // evalue/metric.py:9-10
   RK_CHECK_ARG(K >= 1 && K <= n_items, "k must be in the range [1, num_items]");
-  if (K > kMaxK) return rk::fail(RK_ERR_UNSUPPORTED, "rk_rows_topk_f32: K=%d above the built maximum %d", K, kMaxK);
   if (n_rows == 0) return RK_OK;
   RK_CHECK_ARG(scores && out_scores && out_ids && ws, "null pointer");
   RK_CHECK_ARG(ws_bytes >= rk_rows_topk_ws_bytes(n_rows, K), "workspace too small");
@@ -966,8 +1034,7 @@ int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_str
   for (int i = 0; i < MAXK; ++i) {
     kl.k[i] = i < nk ? k_list_host[i] : 0;
     if (i < nk) {
-      RK_CHECK_ARG(kl.k[i] >= 1 && kl.k[i] <= kMaxK && kl.k[i] <= id_stride,
-                   "k=%d outside [1, min(%d, id_stride)]", kl.k[i], kMaxK);
+      RK_CHECK_ARG(kl.k[i] >= 1 && kl.k[i] <= id_stride, "k=%d outside [1, id_stride = %d]", kl.k[i], id_stride);
       if (kl.k[i] > kmax) kmax = kl.k[i];
     }
   }
@@ -979,9 +1046,12 @@ int rk_rank_metrics_f32(const int32_t *topk_ids, int32_t n_users, int32_t id_str
   else if (kmax <= 32)
     rank_metrics_kernel<1, 32><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
                                                 (double *)ws);
-  else
+  else if (kmax <= kMaxK)
     rank_metrics_kernel<kMaxK / 32, kMaxK><<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax,
                                                         discounts, (double *)ws);
+  else
+    rank_metrics_stream_kernel<<<nb, 256, 0, st>>>(topk_ids, n_users, id_stride, tgt_ptr, tgt_items, kl, nk, kmax, discounts,
+                                                   (double *)ws);
   RK_CHECK_LAUNCH("rank_metrics_kernel");
   rank_metrics_final_kernel<<<1, 1024, 0, st>>>((const double *)ws, nb, nk, (double)mean_denominator,
                                                out, sums_out);

@@ -489,12 +489,13 @@ def test_sparse_pairs_from_the_data_path_equal_the_dense_target():
 
 
 @pytest.mark.parametrize("U,I,D,K", [(300, 1000, 64, 50), (129, 130, 128, 128), (70, 33, 64, 33), (1000, 5000, 64, 100),
+                                     (130, 400, 64, 129), (90, 300, 128, 300),
                                       (65, 400, 64, 64)])
 def test_rankings_longer_than_one_list_vs_oracle(U, I, D, K):
     """K > 32: pages of 32 places, each bounded above by the last entry of the page before.
     Quantised embeddings put long runs of equal scores across the page boundaries; one user has
     every item masked (its ranking is the mask score, by id), some have most.  Ids and scores equal
-    the oracle's; the longest built ranking is 128, beyond it the call refuses."""
+    the oracle's, up to K = the number of items (evalue/metric.py:9-10: any k in [1, num_items])."""
     rng = np.random.default_rng(U + K)
     ue = (np.round(rng.standard_normal((U, D)) * 2) / 2).astype(np.float32)
     ie = (np.round(rng.standard_normal((I, D)) * 2) / 2).astype(np.float32)
@@ -512,16 +513,15 @@ def test_rankings_longer_than_one_list_vs_oracle(U, I, D, K):
     o_s2, o_i2 = eval_oracle.score_topk(ue, ie, K)
     np.testing.assert_array_equal(ids2.cpu().numpy(), o_i2 + 1000)
     np.testing.assert_array_equal(s2.cpu().numpy(), o_s2)
-    if I > 129:
-        with pytest.raises(Exception, match="above the built maximum"):
-            ops.score_topk(dev(ue), dev(ie), 129)
+    with pytest.raises(Exception, match=r"range \[1, num_items\]"):
+        ops.score_topk(dev(ue), dev(ie), I + 1)
 
 
 def test_long_rankings_of_dense_scores_and_their_metrics_vs_oracle():
     """rows_topk and the metrics at k up to 128: ids against a stable sort with heavy ties, the six
     metrics against the oracle's per-user formulas (evalue/metric.py:106-164) on the same ranking."""
     rng = np.random.default_rng(12)
-    for (B, I, K) in ((9, 200, 33), (130, 1000, 100), (40, 128, 128), (300, 700, 64)):
+    for (B, I, K) in ((9, 200, 33), (130, 1000, 100), (40, 128, 128), (300, 700, 64), (70, 500, 129), (33, 260, 260)):
         s = rng.integers(0, 9, size=(B, I)).astype(np.float32)
         vals, ids = ops.rows_topk(dev(s), K)
         order = np.lexsort((np.broadcast_to(np.arange(I), (B, I)), -s), axis=1)[:, :K]
@@ -533,27 +533,34 @@ def test_long_rankings_of_dense_scores_and_their_metrics_vs_oracle():
         tp, tcols = pairs_to_csr(tr, tc, B)
         ks = sorted({5, 20, 33, K})
         got = ops.rank_metrics(ids, dev(tp), dev(tcols), ks).cpu().numpy()
+        if K > 128:
+            # rankings beyond 128 places are walked from memory: for the k that both kernels serve, the same bits
+            short = [k for k in ks if k <= 128]
+            again = ops.rank_metrics(ids, dev(tp), dev(tcols), short).cpu().numpy()
+            assert np.array_equal(again, got[:len(short)])
         want = eval_oracle.metrics_from_topk_sparse(order.astype(np.int32), tp, tcols, ks)
         for j, k in enumerate(ks):
             for m, name in enumerate(METRICS):
                 assert abs(got[j][m] - want[k][name]) <= 1e-5 * max(want[k][name], 1e-3), (B, I, K, k, name)
 
 
-def test_evaluator_with_k_50_vs_oracle():
+@pytest.mark.parametrize("KL", [50, 200])
+def test_evaluator_with_long_rankings_vs_oracle(KL):
+    """k beyond one list (50) and beyond the ranked ids a metrics lane holds in registers (200)."""
     rng = np.random.default_rng(4)
     U, I, D = 900, 2500, 64
     ue = (rng.standard_normal((U, D)) * 0.1).astype(np.float32)
     ie = (rng.standard_normal((I, D)) * 0.1).astype(np.float32)
     tu, ti = rng.integers(0, U, 20000), rng.integers(0, I, 20000)
     vu, vi = rng.integers(0, U, 4000), rng.integers(0, I, 4000)
-    ev = RankingEvaluator((vu, vi), (tu, ti), [10, 50], METRICS, n_users=U)
+    ev = RankingEvaluator((vu, vi), (tu, ti), [10, KL], METRICS, n_users=U)
     res = ev.evaluate(dev(ue), dev(ie))
     ptr, cols = pairs_to_csr(tu, ti, U)
-    _os, o_i = eval_oracle.score_topk(ue, ie, 50, ptr, cols)
-    np.testing.assert_array_equal(ev.topk(dev(ue), dev(ie), 50)[1].cpu().numpy(), o_i)
+    _os, o_i = eval_oracle.score_topk(ue, ie, KL, ptr, cols)
+    np.testing.assert_array_equal(ev.topk(dev(ue), dev(ie), KL)[1].cpu().numpy(), o_i)
     tp, tc = pairs_to_csr(vu, vi, U)
-    want = eval_oracle.metrics_from_topk_sparse(o_i, tp, tc, [10, 50])
-    for k in (10, 50):
+    want = eval_oracle.metrics_from_topk_sparse(o_i, tp, tc, [10, KL])
+    for k in (10, KL):
         for m in METRICS:
             assert abs(float(res[f"{m}@{k}"]) - want[k][m]) <= 1e-5 * max(want[k][m], 1e-3), (m, k)
 
