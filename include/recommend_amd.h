@@ -171,6 +171,15 @@ int rk_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val,
 int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W,
                     const float *b, int32_t D, int32_t n_users, float *Y,
                     void *stream);
+/* The same projection with a workspace (rk_proj_fwd_ws_bytes() bytes, 16-byte aligned; 0 for
+ * shapes it has no use for): for D = 64 and F a multiple of 32 the weights are split once per call
+ * into three bf16 parts in the order the matrix instructions read them, and the product runs on
+ * the bf16 matrix pipe with 256-row workgroup tiles (the error of a product is that of an fp32 dot
+ * product, as for the node-wise layers below).  Other shapes: rk_proj_fwd_f32. */
+size_t rk_proj_fwd_ws_bytes(int32_t n_items, int32_t F, int32_t D);
+int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *W,
+                       const float *b, int32_t D, int32_t n_users, float *Y,
+                       void *ws, size_t ws_bytes, void *stream);
 size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F,
                             int32_t D);
 /* dW = dY[item rows]^T X (D x F), db = column sums of dY over all U+I rows.

@@ -84,6 +84,8 @@ SIGNATURES = {
     "rk_spmm_csr_f32": (c_int32, [P, P, P, c_int32, P, c_int32, P, P, c_float, c_float,
                                   POINTER(SpmmPlan), P]),
     "rk_proj_fwd_f32": (c_int32, [P, c_int32, c_int32, P, P, c_int32, c_int32, P, P]),
+    "rk_proj_fwd_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rk_proj_fwd_ws_f32": (c_int32, [P, c_int32, c_int32, P, P, c_int32, c_int32, P, P, c_size_t, P]),
     "rk_proj_bwd_ws_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "rk_proj_bwd_f32": (c_int32, [P, c_int32, c_int32, P, c_int32, c_int32, P, P, P, c_size_t, P]),
     "rk_dense_fwd_f32": (c_int32, [P, P, P, P, P, P, P, c_float, c_uint64, P, P, c_int64, c_int32,

@@ -87,6 +87,26 @@ __device__ __forceinline__ void mfma_split3_shared_a(const SplitN<NV> &a, const 
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b1.h[s4], acc1, 0, 0, 0);
   }
 }
+// Four independent products (two A operands x two B operands), one MFMA of each in turn.  A wavefront
+// that is alone on its SIMD needs this many chains in flight: an MFMA that accumulates onto a result
+// can issue only well after the MFMA that produces it has left the pipe, and with two chains the pipe
+// idles more than half of the time.  Per accumulator the operations and their order are mfma_split3's.
+template <int NV>
+__device__ __forceinline__ void mfma_split3_2x2(const SplitN<NV> &a0, const SplitN<NV> &a1, const SplitN<NV> &b0,
+                                                const SplitN<NV> &b1, floatx16 &c00, floatx16 &c01, floatx16 &c10,
+                                                floatx16 &c11) {
+#define RK_MFMA4(PA, PB)                                                                 \
+  c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.PA[s4], b0.PB[s4], c00, 0, 0, 0);     \
+  c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.PA[s4], b1.PB[s4], c01, 0, 0, 0);     \
+  c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.PA[s4], b0.PB[s4], c10, 0, 0, 0);     \
+  c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.PA[s4], b1.PB[s4], c11, 0, 0, 0);
+#pragma unroll
+  for (int s4 = 0; s4 < NV / 8; ++s4) {
+    RK_MFMA4(l, h) RK_MFMA4(h, l) RK_MFMA4(m, m) RK_MFMA4(m, h) RK_MFMA4(h, m) RK_MFMA4(h, h)
+  }
+#undef RK_MFMA4
+}
+
 // the same split for four values that leave as three 8-byte packs (h, m, l of x, y, z, w)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_quad(float x, float y, float z, float w, u32x2 &h, u32x2 &m, u32x2 &l) {

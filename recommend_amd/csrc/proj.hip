@@ -9,14 +9,15 @@
 // Backward: dW = dY_items^T X is a GEMM whose reduction runs over the items;
 // it is cut into item slices whose 64 x 128 partial tiles are summed in slice
 // order by a second kernel (deterministic, no float atomics).
+#include "bf16x3.h"
 #include "common.h"
 #include "slab_reduce.h"
 
 namespace {
 
 using rk::kWave;
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
+using rk::floatx16;
+using rk::floatx4;
 
 constexpr int BM = 128, BN = 64, BK = 32;
 constexpr int LDA = BK + 4;  // padded LDS row (floats): conflict-free b128 reads
@@ -115,6 +116,159 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const float *__restrict__
     }
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Forward for D = 64 and F a multiple of 32 on the bf16 matrix pipe (three-way operand splits,
+// bf16x3.h) with TALL workgroup tiles.  What bounds a projection of 4096-wide features is the rate
+// at which the L1s can be filled (every workgroup streams its rows of X once and re-reads the
+// whole of W): a 128-row tile re-reads 0.5 GB of weights beside the 1.03 GB of features, a 256-row
+// tile half of that, and 247 workgroups are one round on 256 CUs.
+//   * X: 256 rows x 32 columns per stage by LDS-DMA (pieces of 1 KB, XOR-swizzled through the
+//     choice of the global piece a lane fetches: the 32-byte fragment reads of 16 consecutive
+//     rows fall on 16 different bank groups), three stages; each computing wavefront reads its
+//     own 64 rows.
+//   * W: split ONCE per call into bf16 planes laid out in fragment order (proj_split_w_kernel), so
+//     a stage's 12 KB chunk lands in LDS by DMA and is read as it lies; shared by the four
+//     wavefronts (one barrier per stage, which also says that everybody is done with the buffer
+//     the next DMA overwrites).
+// The DMAs are inline assembly (no register destination; the kernel's own s_waitcnt vmcnt(N)
+// builtin in front of the barrier is the synchronisation; M0 written one wait state ahead).
+constexpr int PR = 256;                 // rows of X per workgroup
+constexpr int PK = 32;                  // columns of X per stage
+constexpr int PST = 3;                  // stages in the ring
+constexpr int PXB = PR * PK * 4;        // bytes of X per stage (8 KB per wavefront)
+constexpr int PWB = 3 * 2 * 2 * 64 * 16;   // bytes of split weights per stage: [part][k16][half][col][8 bf16]
+constexpr int PNX = 8, PNW = 3;         // DMA instructions per wavefront and stage (X, W)
+
+__global__ __launch_bounds__(256) void proj_split_w_kernel(const float *__restrict__ W, int32_t F,
+                                                           char *__restrict__ Wp) {
+  // thread -> (stage c, k16 s, half h, column): eight consecutive k of one row of W
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = (int64_t)(F / PK) * 2 * 2 * 64;
+  if (t >= n) return;
+  const int col = (int)(t & 63), h = (int)((t >> 6) & 1), s2 = (int)((t >> 7) & 1);
+  const int64_t c = t >> 8;
+  const float *src = W + (int64_t)col * F + c * PK + s2 * 16 + h * 8;
+  const floatx4 v0 = *reinterpret_cast<const floatx4 *>(src), v1 = *reinterpret_cast<const floatx4 *>(src + 4);
+  const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  rk::SplitN<8> sp;
+  rk::split3(x, sp);
+  char *dst = Wp + c * PWB + (size_t)((s2 * 2 + h) * 1024 + col * 16);
+  *reinterpret_cast<rk::bf16x8 *>(dst) = sp.h[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 4096) = sp.m[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 8192) = sp.l[0];
+}
+
+__global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restrict__ X, int32_t n_items, int32_t F,
+                                                            const char *__restrict__ Wp, const float *__restrict__ b,
+                                                            float *__restrict__ Yitems) {
+  __shared__ __attribute__((aligned(16))) char plds[PST * (PXB + PWB)];
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int64_t row0 = (int64_t)blockIdx.x * PR;
+  const int n_steps = F / PK;
+
+  if (wave == 4) {
+    // The producer: a fifth wavefront that only issues the DMAs.  A DMA instruction is accepted at
+    // the rate memory delivers, and issue is in order: a wavefront that stages its own rows sits in
+    // front of its DMAs for longer than its arithmetic takes and the memory queues run dry while it
+    // computes (measured: 289 us; a bare stream of the same tiles: 183 us).  Here the four computing
+    // wavefronts never wait for an issue slot, and this one never does anything else.
+    // Piece i of a stage: rows 8i .. 8i+7 of the workgroup's 256, eight 16-byte pieces each; LDS
+    // position p of row r receives global piece p ^ ((r >> 1) & 7).
+    uint32_t voff[4 * PNX];
+#pragma unroll
+    for (int i = 0; i < 4 * PNX; ++i) {
+      const int r = 8 * i + lane / 8;
+      int64_t g = row0 + r;
+      g = g < n_items ? g : n_items - 1;      // rows past the end re-read the last row; they are not stored
+      voff[i] = (uint32_t)((g - row0) * F * 4 + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)plds);
+    const uint32_t woff = (uint32_t)(lane * 16);
+    auto issue = [&](int st) {
+      const uint32_t buf = lds0 + (uint32_t)((st % PST) * (PXB + PWB));
+      const char *xb = reinterpret_cast<const char *>(X + row0 * F + (int64_t)st * PK);
+      const char *wb = Wp + (int64_t)st * PWB;
+#pragma unroll
+      for (int i = 0; i < 4 * PNW; ++i)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(woff + (uint32_t)(i * 1024)), "s"(wb), "s"(buf + (uint32_t)(PXB + i * 1024)) : "memory", "m0");
+#pragma unroll
+      for (int i = 0; i < 4 * PNX; ++i)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(voff[i]), "s"(xb), "s"(buf + (uint32_t)(i * 1024)) : "memory", "m0");
+    };
+    constexpr int kPerStage = 4 * (PNX + PNW);     // 44 of the 63 operations the counter holds
+    issue(0);
+    if (n_steps > 1) issue(1);
+    for (int st = 0; st < n_steps; ++st) {
+      // stage st has landed: the only DMAs issued after it are those of stage st + 1
+      if (st + 1 < n_steps)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (kPerStage & 15) | ((kPerStage >> 4) << 14));
+      else
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();      // stage st is there, and everybody is past stage st - 1, whose buffer comes next
+      if (st + 2 < n_steps) issue(st + 2);
+    }
+    return;
+  }
+
+  const int col = lane & 31, half = lane >> 5;
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
+
+  for (int st = 0; st < n_steps; ++st) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");       // (the tiles change behind the compiler's back)
+    const char *xs = plds + (st % PST) * (PXB + PWB) + wave * 8192;
+    const char *ws = plds + (st % PST) * (PXB + PWB) + PXB;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      rk::SplitN<8> bw[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const char *p = ws + (s2 * 2 + half) * 1024 + (cb * 32 + col) * 16;
+        bw[cb].h[0] = *reinterpret_cast<const rk::bf16x8 *>(p);
+        bw[cb].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 4096);
+        bw[cb].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 8192);
+      }
+      rk::SplitN<8> ax[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int r = 32 * rb + col, q = 4 * s2 + 2 * half, sw = (r >> 1) & 7;
+        const floatx4 v0 = *reinterpret_cast<const floatx4 *>(xs + r * 128 + ((q ^ sw) * 16));
+        const floatx4 v1 = *reinterpret_cast<const floatx4 *>(xs + r * 128 + (((q + 1) ^ sw) * 16));
+        const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        rk::split3(x, ax[rb]);
+      }
+      // four chains in flight: the wavefront is alone on its SIMD
+      rk::mfma_split3_2x2(ax[0], ax[1], bw[0], bw[1], acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
+  }
+  // C layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = 32 * cb + col;
+    const float bias = b ? b[n] : 0.0f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = row0 + 64 * wave + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < n_items) Yitems[m * 64 + n] = acc[rb][cb][r] + bias;
+      }
+  }
+}
+
+inline bool tall_fwd_shape(int32_t F, int32_t D) { return D == 64 && F % PK == 0 && F >= 2 * PK; }
 
 // dW partial: workgroup (f-tile, d-tile, slice) reduces items [i_lo, i_hi).
 // A[i = d][k = item] = dY[item][d], B[k = item][j = f] = X[item][f].
@@ -233,6 +387,36 @@ int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, 
     proj_fwd_kernel<<<grid, 256, 0, st>>>(X, n_items, F, W, b, D, Y + nu);
     RK_CHECK_LAUNCH("proj_fwd_kernel");
   }
+  return RK_OK;
+}
+
+size_t rk_proj_fwd_ws_bytes(int32_t n_items, int32_t F, int32_t D) {
+  if (n_items <= 0 || F <= 0 || D <= 0 || !tall_fwd_shape(F, D)) return 0;
+  return (size_t)(F / PK) * PWB;
+}
+
+int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *W, const float *b,
+                       int32_t D, int32_t n_users, float *Y, void *ws, size_t ws_bytes, void *stream) {
+  if (n_items <= 0 || F <= 0 || D <= 0 || !tall_fwd_shape(F, D))
+    return rk_proj_fwd_f32(X, n_items, F, W, b, D, n_users, Y, stream);
+  RK_CHECK_ARG(n_users >= 0, "bad sizes");
+  RK_CHECK_ARG(X && W && Y && ws, "null pointer");
+  RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(W) && rk::aligned16(Y) && rk::aligned16(b) && rk::aligned16(ws),
+               "matrices, bias and workspace must be 16-byte aligned");
+  RK_CHECK_ARG(ws_bytes >= rk_proj_fwd_ws_bytes(n_items, F, D), "workspace too small");
+  // (the kernel addresses a workgroup's rows with 32-bit byte offsets from its first row)
+  RK_CHECK_ARG((int64_t)PR * F * 4 < ((int64_t)1 << 32), "feature width too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nu = (int64_t)n_users * D;
+  if (nu > 0) {
+    proj_fill_users_kernel<<<(unsigned)rk::ceil_div(nu / 4, 256), 256, 0, st>>>(b, D, nu / 4, Y);
+    RK_CHECK_LAUNCH("proj_fill_users_kernel");
+  }
+  const int64_t nt = (int64_t)(F / PK) * 256;
+  proj_split_w_kernel<<<(unsigned)rk::ceil_div(nt, 256), 256, 0, st>>>(W, F, (char *)ws);
+  RK_CHECK_LAUNCH("proj_split_w_kernel");
+  proj_fwd_tall_kernel<<<(unsigned)rk::ceil_div(n_items, PR), 320, 0, st>>>(X, n_items, F, (const char *)ws, b, Y + nu);
+  RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
   return RK_OK;
 }
 

@@ -264,8 +264,11 @@ class _Proj(torch.autograd.Function):
         if weight.shape[1] != F:
             raise ValueError(f"weight is {tuple(weight.shape)}, features are {F} wide")
         y = torch.empty((n_users + n_items, D), dtype=torch.float32, device=x_items.device)
-        _ffi.call("rk_proj_fwd_f32", ptr(x_items), c_int32(n_items), c_int32(F), ptr(weight),
-                  ptr(bias_c), c_int32(D), c_int32(n_users), ptr(y), stream_ptr(y.device))
+        ws_bytes = _ffi.load().rk_proj_fwd_ws_bytes(n_items, F, D)     # the weights' split parts (0: shapes the plain kernel takes)
+        ws = torch.empty(max(ws_bytes, 16) // 4 + 4, dtype=torch.float32, device=y.device)
+        _ffi.call("rk_proj_fwd_ws_f32", ptr(x_items), c_int32(n_items), c_int32(F), ptr(weight),
+                  ptr(bias_c), c_int32(D), c_int32(n_users), ptr(y), ptr(ws), c_size_t(ws.numel() * 4),
+                  stream_ptr(y.device))
         ctx.save_for_backward(x_items)
         ctx.n_users, ctx.D, ctx.has_bias = n_users, D, bias is not None
         return y

@@ -1,4 +1,5 @@
-"""GPU parity: modality projection (fp32 MFMA GEMM) forward and backward against
+"""GPU parity: modality projection (MFMA GEMMs: three-way bf16 splits with 256-row tiles at D = 64 and
+feature widths that are multiples of 32, fp32-input MFMA otherwise) forward and backward against
 a float64 restatement of nn.Linear over the zero-padded feature matrix
 (model/Main_Model.py:65-74,154).  Tolerance: 1e-5 of the output scale."""
 import numpy as np
@@ -12,7 +13,10 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("U,I,F,D", [(7, 130, 384, 64), (50, 1000, 4096, 64), (0, 257, 100, 64),
-                                      (33, 65, 36, 128), (10, 300, 512, 32)])
+                                      (33, 65, 36, 128), (10, 300, 512, 32),
+                                      # the tall-tile kernel's edges: two and three stages, one row, rows just
+                                      # below / at / above a workgroup's 256, several workgroups with a ragged last one
+                                      (3, 1, 64, 64), (0, 255, 96, 64), (5, 256, 64, 64), (2, 257, 160, 64), (9, 1500, 1024, 64)])
 def test_projection_forward_backward(U, I, F, D):
     rng = np.random.default_rng(F + D)
     X = rng.standard_normal((I, F)).astype(np.float32)
