@@ -357,6 +357,190 @@ __global__ __launch_bounds__(256) void proj_dw_kernel(const float *__restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// dW = dY_items^T X in the same form: D = 64, the reduction over the items on the bf16 matrix pipe.
+// A workgroup owns all 64 rows of dW x FT feature columns (FT = 512 or 384: four wavefronts x NF
+// blocks of 32) and one slice of the items; a stage is 16 items x FT columns of X (32 or 24 KB by
+// LDS-DMA from a fifth, producer wavefront, as in the forward) plus the stage's 6 KB of dY, which is
+// split ONCE per call into bf16 parts laid out in fragment order (proj_split_dy_kernel; items past
+// the end are zero there, so the rows of X re-read in their place add nothing).  X enters the MFMA
+// as the B operand, eight ITEMS per lane at one feature: eight 4-byte LDS reads per block of 32
+// features, rows 8..15 of a stage shifted by 128 bytes (through the global piece a DMA lane fetches)
+// so that the two halves of a wavefront read different banks.  Per slice a 64 x F partial result;
+// the slices are summed in slice order (slab_reduce): deterministic, no float atomics.
+constexpr int QI = 16;                              // items per stage
+constexpr int QYB = 3 * 2 * 2 * 32 * 16;            // bytes of split dY per stage: [part][d block][half][d][8 items]
+
+__global__ __launch_bounds__(256) void proj_split_dy_kernel(const float *__restrict__ dY, int32_t n_items,
+                                                            int64_t n_stages, char *__restrict__ Yp) {
+  // thread -> (stage, d block, half, d): eight consecutive items at one column of dY
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_stages * 128) return;
+  const int d = (int)(t & 31), h = (int)((t >> 5) & 1), db = (int)((t >> 6) & 1);
+  const int64_t st = t >> 7;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t i = st * QI + 8 * h + j;
+    x[j] = i < n_items ? dY[i * 64 + 32 * db + d] : 0.0f;
+  }
+  rk::SplitN<8> sp;
+  rk::split3(x, sp);
+  char *dst = Yp + st * QYB + (size_t)((db * 2 + h) * 512 + d * 16);
+  *reinterpret_cast<rk::bf16x8 *>(dst) = sp.h[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 2048) = sp.m[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 4096) = sp.l[0];
+}
+
+template <int NF>
+__global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restrict__ X, int32_t n_items, int32_t F,
+                                                           const char *__restrict__ Yp, int32_t stages_per_slice,
+                                                           int64_t n_stages, float *__restrict__ slab) {
+  constexpr int FT = 128 * NF;                       // feature columns per workgroup
+  constexpr int XB = QI * FT * 4;                    // bytes of X per stage
+  constexpr int NX = XB / 1024, NY = QYB / 1024;     // DMA instructions per stage
+  constexpr int PPRW = FT / 4;                       // 16-byte pieces per row of a stage
+  __shared__ __attribute__((aligned(16))) char qlds[PST * (XB + QYB)];
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int32_t f0 = blockIdx.x * FT;
+  const int64_t s_lo = (int64_t)blockIdx.y * stages_per_slice;
+  const int64_t s_hi = s_lo + stages_per_slice < n_stages ? s_lo + stages_per_slice : n_stages;
+  const int n_steps = (int)(s_hi - s_lo);
+
+  if (wave == 4) {
+    // the producer (see proj_fwd_tall_kernel).  DMA instruction j of a stage fills LDS bytes
+    // [1024 j, 1024 j + 1024): position p of row r receives global piece p ^ (8 * (r >> 3)).
+    int rowj[NX], piecej[NX];
+    uint32_t voff[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int e = 64 * j + lane;
+      rowj[j] = e / PPRW;
+      piecej[j] = (e % PPRW) ^ (8 * (rowj[j] >> 3));
+      voff[j] = (uint32_t)(rowj[j] * F * 4 + piecej[j] * 16);
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)qlds);
+    const uint32_t yoff = (uint32_t)(lane * 16);
+    auto issue = [&](int st) {
+      const uint32_t buf = lds0 + (uint32_t)((st % PST) * (XB + QYB));
+      const int64_t i0 = (s_lo + st) * QI;
+      const char *yb = Yp + (s_lo + st) * QYB;
+#pragma unroll
+      for (int j = 0; j < NY; ++j)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(yoff + (uint32_t)(j * 1024)), "s"(yb), "s"(buf + (uint32_t)(XB + j * 1024)) : "memory", "m0");
+      if (i0 + QI <= n_items) {
+        const char *xb = reinterpret_cast<const char *>(X + i0 * F + f0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j)
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                       : : "v"(voff[j]), "s"(xb), "s"(buf + (uint32_t)(j * 1024)) : "memory", "m0");
+      } else {
+        // the last stage of the table: rows past the end re-read the last row (their dY parts are zero)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          int64_t g = i0 + rowj[j];
+          g = g < n_items ? g : n_items - 1;
+          const char *addr = reinterpret_cast<const char *>(X + g * F + f0) + piecej[j] * 16;
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       : : "v"(addr), "s"(buf + (uint32_t)(j * 1024)) : "memory", "m0");
+        }
+      }
+    };
+    constexpr int kPerStage = NX + NY;               // 38 or 30 of the 63 operations the counter holds
+    if (n_steps > 0) issue(0);
+    if (n_steps > 1) issue(1);
+    for (int st = 0; st < n_steps; ++st) {
+      if (st + 1 < n_steps)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (kPerStage & 15) | ((kPerStage >> 4) << 14));
+      else
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+      if (st + 2 < n_steps) issue(st + 2);
+    }
+    return;
+  }
+
+  const int col = lane & 31, half = lane >> 5;
+  floatx16 acc[2][NF];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int fb = 0; fb < NF; ++fb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[db][fb][r] = 0.0f;
+
+  for (int st = 0; st < n_steps; ++st) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");       // (the tiles change behind the compiler's back)
+    const char *xs = qlds + (st % PST) * (XB + QYB);
+    const char *ys = xs + XB;
+    rk::SplitN<8> ay[2], bx[NF];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const char *p = ys + (db * 2 + half) * 512 + col * 16;
+      ay[db].h[0] = *reinterpret_cast<const rk::bf16x8 *>(p);
+      ay[db].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 2048);
+      ay[db].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 4096);
+    }
+#pragma unroll
+    for (int fb = 0; fb < NF; ++fb) {
+      const int f = wave * (32 * NF) + 32 * fb + col;
+      const char *p = xs + (8 * half) * (FT * 4) + (((f >> 2) ^ (8 * half)) * 16) + (f & 3) * 4;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float *>(p + j * (FT * 4));
+      rk::split3(x, bx[fb]);
+    }
+    // 2 * NF chains in flight, one MFMA of each in turn (per accumulator: mfma_split3's operations and order)
+#define RK_DW_TERM(PA, PB)                                                                                    \
+  _Pragma("unroll") for (int fb = 0; fb < NF; ++fb) {                                                          \
+    acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[0].PA[0], bx[fb].PB[0], acc[0][fb], 0, 0, 0);      \
+    acc[1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[1].PA[0], bx[fb].PB[0], acc[1][fb], 0, 0, 0);      \
+  }
+    RK_DW_TERM(l, h) RK_DW_TERM(h, l) RK_DW_TERM(m, m) RK_DW_TERM(m, h) RK_DW_TERM(h, m) RK_DW_TERM(h, h)
+#undef RK_DW_TERM
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
+  }
+  // slab[slice][d][f]; C layout: column (f) = lane & 31, row (d) = (r & 3) + 8 * (r >> 2) + 4 * half
+  float *out = slab + (int64_t)blockIdx.y * 64 * F;
+#pragma unroll
+  for (int fb = 0; fb < NF; ++fb) {
+    const int32_t f = f0 + wave * (32 * NF) + 32 * fb + col;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = 32 * db + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[(int64_t)d * F + f] = acc[db][fb][r];
+      }
+  }
+}
+
+// feature columns per workgroup of the tall dW kernel for a shape (0: the plain kernel takes it)
+inline int tall_dw_ft(int32_t F, int32_t D) {
+  if (D != 64) return 0;
+  return F % 512 == 0 ? 512 : (F % 384 == 0 ? 384 : 0);
+}
+struct TallDw {
+  int ft, slices, stages_per_slice;
+  int64_t n_stages;
+};
+inline TallDw tall_dw_plan(int32_t n_items, int32_t F, int32_t D) {
+  TallDw p{};
+  p.ft = tall_dw_ft(F, D);
+  if (p.ft == 0 || n_items <= 0) return p;
+  p.n_stages = rk::ceil_div(n_items, QI);
+  const int64_t tiles = F / p.ft;
+  int64_t want = rk::ceil_div(248, tiles);                       // about one workgroup per CU
+  if (want > p.n_stages) want = p.n_stages;
+  p.stages_per_slice = (int)rk::ceil_div(p.n_stages, want);
+  p.slices = (int)rk::ceil_div(p.n_stages, p.stages_per_slice);
+  return p;
+}
+
 inline int dw_slices(int32_t n_items, int32_t F, int32_t D) {
   const int64_t tiles = rk::ceil_div(F, WF) * rk::ceil_div(D, 64);
   int64_t s = rk::ceil_div(1024, tiles);
@@ -422,9 +606,11 @@ int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *
 
 size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F, int32_t D) {
   if (n_items < 0 || n_users < 0 || F <= 0 || D <= 0) return 0;
-  // dW slabs + segment sums; the bias partials reuse the same buffer afterwards
-  const int slices = dw_slices(n_items, F, D);
-  const size_t slab = ((size_t)slices * D * F + rk::slab_tmp_floats(slices, (int64_t)D * F)) * sizeof(float);
+  // dW slabs + segment sums (+ the split parts of dY for the tall kernel); the bias partials reuse the buffer afterwards
+  const TallDw tp = tall_dw_plan(n_items, F, D);
+  const int slices = tp.ft ? tp.slices : dw_slices(n_items, F, D);
+  size_t slab = ((size_t)slices * D * F + rk::slab_tmp_floats(slices, (int64_t)D * F)) * sizeof(float);
+  if (tp.ft) slab = ((slab + 255) & ~(size_t)255) + (size_t)tp.n_stages * QYB;
   const int64_t nb = rk::ceil_div((int64_t)n_items + n_users, rk::kColsumRows);
   const size_t bias = ((size_t)nb * D + rk::slab_tmp_floats((int32_t)nb, D)) * sizeof(float);
   return slab > bias ? slab : bias;
@@ -439,9 +625,26 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
   RK_CHECK_ARG(ws_bytes >= rk_proj_bwd_ws_bytes(n_items, n_users, F, D), "workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t nW = (int64_t)D * F;
-  const int slices = dw_slices(n_items, F, D);
+  const TallDw tp = tall_dw_plan(n_items, F, D);
+  const int slices = tp.ft ? tp.slices : dw_slices(n_items, F, D);
   float *slab = (float *)ws;
-  if (n_items > 0) {
+  if (n_items > 0 && tp.ft) {
+    RK_CHECK_ARG(rk::aligned16(X) && rk::aligned16(dY) && rk::aligned16(ws), "matrices and workspace must be 16-byte aligned");
+    RK_CHECK_ARG((int64_t)QI * F * 4 < ((int64_t)1 << 32), "feature width too large");
+    const size_t slab_bytes = ((size_t)slices * nW + rk::slab_tmp_floats(slices, nW)) * sizeof(float);
+    char *yp = (char *)ws + ((slab_bytes + 255) & ~(size_t)255);
+    proj_split_dy_kernel<<<(unsigned)rk::ceil_div(tp.n_stages * 128, 256), 256, 0, st>>>(dY + (int64_t)n_users * D, n_items,
+                                                                                          tp.n_stages, yp);
+    RK_CHECK_LAUNCH("proj_split_dy_kernel");
+    dim3 grid((unsigned)(F / tp.ft), (unsigned)slices);
+    if (tp.ft == 512)
+      proj_dw_tall_kernel<4><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
+    else
+      proj_dw_tall_kernel<3><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
+    RK_CHECK_LAUNCH("proj_dw_tall_kernel");
+    const int rc = rk::slab_reduce(slab, slices, nW, nW, slab + (size_t)slices * nW, dW, st);
+    if (rc != RK_OK) return rc;
+  } else if (n_items > 0) {
     const int32_t ips = (int32_t)(rk::ceil_div(rk::ceil_div(n_items, slices), WI) * WI);
     dim3 grid((unsigned)rk::ceil_div(F, WF), (unsigned)rk::ceil_div(D, 64), (unsigned)slices);
     proj_dw_kernel<<<grid, 256, 0, st>>>(X, n_items, F, dY + (int64_t)n_users * D, D, ips, slab);

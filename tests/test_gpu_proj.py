@@ -16,7 +16,10 @@ DEV = "cuda:0"
                                       (33, 65, 36, 128), (10, 300, 512, 32),
                                       # the tall-tile kernel's edges: two and three stages, one row, rows just
                                       # below / at / above a workgroup's 256, several workgroups with a ragged last one
-                                      (3, 1, 64, 64), (0, 255, 96, 64), (5, 256, 64, 64), (2, 257, 160, 64), (9, 1500, 1024, 64)])
+                                      (3, 1, 64, 64), (0, 255, 96, 64), (5, 256, 64, 64), (2, 257, 160, 64), (9, 1500, 1024, 64),
+                                      # the tall weight-gradient kernel: 384- and 512-column workgroups, one item, item counts
+                                      # around a stage of 16, more stages than slices
+                                      (1, 1, 384, 64), (0, 15, 512, 64), (4, 16, 768, 64), (2, 17, 1536, 64), (3, 5000, 384, 64)])
 def test_projection_forward_backward(U, I, F, D):
     rng = np.random.default_rng(F + D)
     X = rng.standard_normal((I, F)).astype(np.float32)
