@@ -64,10 +64,11 @@ __device__ __forceinline__ void mfma_split3(const SplitN<NV> &a, const SplitN<NV
   }
 }
 
-// Two independent products that share one operand, their MFMAs issued alternately: an MFMA that
-// accumulates onto the result of the one just before it waits for that result (half the issue
-// rate of the matrix pipe for a single chain).  Each accumulator sees the same operations in the
-// same order as with mfma_split3: the results are the same bits.
+// Two independent products that share one operand, their MFMAs issued alternately.  A chain of these
+// MFMAs on ONE accumulator issues nearly at the pipe's rate (36 cycles each against 34 with several
+// chains in flight, measured with one wavefront per SIMD); alternating gives those few per cent and
+// lets the operand fragments of the second product be read while the first computes.  Each
+// accumulator sees the same operations in the same order as with mfma_split3: the same bits.
 template <int NV>
 __device__ __forceinline__ void mfma_split3_shared_a(const SplitN<NV> &a, const SplitN<NV> &b0, const SplitN<NV> &b1,
                                                      floatx16 &acc0, floatx16 &acc1) {
@@ -87,10 +88,9 @@ __device__ __forceinline__ void mfma_split3_shared_a(const SplitN<NV> &a, const 
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s4], b1.h[s4], acc1, 0, 0, 0);
   }
 }
-// Four independent products (two A operands x two B operands), one MFMA of each in turn.  A wavefront
-// that is alone on its SIMD needs this many chains in flight: an MFMA that accumulates onto a result
-// can issue only well after the MFMA that produces it has left the pipe, and with two chains the pipe
-// idles more than half of the time.  Per accumulator the operations and their order are mfma_split3's.
+// Four independent products (two A operands x two B operands), one MFMA of each in turn (see above:
+// a few per cent over one chain after the other).  Per accumulator the operations and their order
+// are mfma_split3's.
 template <int NV>
 __device__ __forceinline__ void mfma_split3_2x2(const SplitN<NV> &a0, const SplitN<NV> &a1, const SplitN<NV> &b0,
                                                 const SplitN<NV> &b1, floatx16 &c00, floatx16 &c01, floatx16 &c10,

@@ -248,7 +248,6 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
         const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         rk::split3(x, ax[rb]);
       }
-      // four chains in flight: the wavefront is alone on its SIMD
       rk::mfma_split3_2x2(ax[0], ax[1], bw[0], bw[1], acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
@@ -494,7 +493,7 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
       for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float *>(p + j * (FT * 4));
       rk::split3(x, bx[fb]);
     }
-    // 2 * NF chains in flight, one MFMA of each in turn (per accumulator: mfma_split3's operations and order)
+    // one MFMA of each accumulator in turn (per accumulator: mfma_split3's operations and order)
 #define RK_DW_TERM(PA, PB)                                                                                    \
   _Pragma("unroll") for (int fb = 0; fb < NF; ++fb) {                                                          \
     acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[0].PA[0], bx[fb].PB[0], acc[0][fb], 0, 0, 0);      \
