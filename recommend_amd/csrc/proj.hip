@@ -1,10 +1,13 @@
-// Modality projection Y = [b ; X W^T + b] and its weight/bias gradients on the
-// fp32 matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+// Modality projection Y = [b ; X W^T + b] and its weight/bias gradients on the matrix cores, gfx950:
+// at D = 64 (feature widths that are multiples of 32; of 384 or 512 for the gradient) on three-way
+// bf16 splits with tall workgroup tiles and a wavefront that only issues the DMAs
+// (proj_fwd_tall_kernel, proj_dw_tall_kernel, further down); every other shape on fp32 operands
+// (v_mfma_f32_32x32x2_f32: proj_fwd_kernel, proj_dw_kernel).
 //
 // The reference pads the item feature matrix with one all-zero row per user
 // and runs nn.Linear over all U+I rows; a zero row times W is exactly zero, so
 // the user rows of the output are the bias and only the I item rows need a
-// GEMM.  Forward: 128 x 64 output tile per workgroup (4 wavefronts x 32 rows),
+// GEMM.  fp32-operand forward: 128 x 64 output tile per workgroup (4 wavefronts x 32 rows),
 // K streamed 32 columns at a time through double-buffered, padded LDS tiles.
 // Backward: dW = dY_items^T X is a GEMM whose reduction runs over the items;
 // it is cut into item slices whose 64 x 128 partial tiles are summed in slice

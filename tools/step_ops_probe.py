@@ -46,7 +46,7 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 import traceback  # noqa: E402
@@ -75,5 +75,9 @@ torch.cuda.synchronize()
 for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total):
     if e.key.startswith("aten::") and e.device_time_total > 0:
         print(f"{e.key:28s} x{e.count:3d}  {e.device_time_total:8.1f} us")
+print("-- copies, fills and their shapes, in launch order")
+for e in prof.events():
+    if e.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::add_", "aten::ones_like") and e.device_time_total > 0:
+        print(f"   {e.name:18s} {e.device_time_total:6.1f} us  shapes {e.input_shapes}")
 for (name, where), n in sorted(sites.items()):
     print(f"{name:12s} x{n:3d}  {where}")
