@@ -165,12 +165,16 @@ __global__ __launch_bounds__(256) void proj_split_w_kernel(const float *__restri
 
 __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restrict__ X, int32_t n_items, int32_t F,
                                                             const char *__restrict__ Wp, const float *__restrict__ b,
-                                                            float *__restrict__ Yitems) {
+                                                            int32_t steps_per_split, float *__restrict__ Yitems) {
+  // blockIdx.y: which part of the feature columns (stages st_lo ..) this workgroup reduces over.  With
+  // one part the result goes to Yitems with the bias; with several, part y's partial sums go to
+  // Yitems + y * n_items * 64 (a slab in the workspace), and proj_sum_parts_kernel adds them in order.
   __shared__ __attribute__((aligned(16))) char plds[PST * (PXB + PWB)];
   const int tid = threadIdx.x, lane = tid % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int64_t row0 = (int64_t)blockIdx.x * PR;
-  const int n_steps = F / PK;
+  const int st_lo = blockIdx.y * steps_per_split;
+  const int n_steps = min(steps_per_split, F / PK - st_lo);
 
   if (wave == 4) {
     // The producer: a fifth wavefront that only issues the DMAs.  A DMA instruction is accepted at
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
     const uint32_t woff = (uint32_t)(lane * 16);
     auto issue = [&](int st) {
       const uint32_t buf = lds0 + (uint32_t)((st % PST) * (PXB + PWB));
-      const char *xb = reinterpret_cast<const char *>(X + row0 * F + (int64_t)st * PK);
-      const char *wb = Wp + (int64_t)st * PWB;
+      const char *xb = reinterpret_cast<const char *>(X + row0 * F + (int64_t)(st_lo + st) * PK);
+      const char *wb = Wp + (int64_t)(st_lo + st) * PWB;
 #pragma unroll
       for (int i = 0; i < 4 * PNW; ++i)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -256,18 +260,39 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
   }
   // C layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half
+  float *out = Yitems + (int64_t)blockIdx.y * n_items * 64;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int n = 32 * cb + col;
-    const float bias = b ? b[n] : 0.0f;
+    const float bias = (b && gridDim.y == 1) ? b[n] : 0.0f;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = row0 + 64 * wave + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < n_items) Yitems[m * 64 + n] = acc[rb][cb][r] + bias;
+        if (m < n_items) out[m * 64 + n] = acc[rb][cb][r] + bias;
       }
   }
+}
+
+// Y = bias + part 0 + part 1 + ... (in this order), four columns per thread
+__global__ __launch_bounds__(256) void proj_sum_parts_kernel(const float *__restrict__ parts, int32_t n_parts, int64_t n4,
+                                                             const float *__restrict__ b, float *__restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  floatx4 v = {0.f, 0.f, 0.f, 0.f};
+  if (b) v = *reinterpret_cast<const floatx4 *>(b + (i * 4) % 64);
+  for (int32_t p = 0; p < n_parts; ++p) v += reinterpret_cast<const floatx4 *>(parts)[(int64_t)p * n4 + i];
+  reinterpret_cast<floatx4 *>(Y)[i] = v;
+}
+
+// Parts of the feature columns a forward launch is cut into: few row tiles (a small item table) would
+// leave most CUs without a workgroup, and a CU's L1 fills at a fixed rate however few of them work.
+inline int tall_fwd_parts(int32_t n_items, int32_t F) {
+  const int64_t tiles = rk::ceil_div(n_items, PR), steps = F / PK;
+  int64_t parts = 256 / tiles;                   // one workgroup per CU at most
+  if (parts > steps / 8) parts = steps / 8;      // eight stages per part at least
+  return (int)(parts < 1 ? 1 : parts);
 }
 
 inline bool tall_fwd_shape(int32_t F, int32_t D) { return D == 64 && F % PK == 0 && F >= 2 * PK; }
@@ -578,7 +603,8 @@ int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, 
 
 size_t rk_proj_fwd_ws_bytes(int32_t n_items, int32_t F, int32_t D) {
   if (n_items <= 0 || F <= 0 || D <= 0 || !tall_fwd_shape(F, D)) return 0;
-  return (size_t)(F / PK) * PWB;
+  const int parts = tall_fwd_parts(n_items, F);
+  return (size_t)(F / PK) * PWB + (parts > 1 ? (size_t)parts * n_items * 64 * sizeof(float) : 0);
 }
 
 int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *W, const float *b,
@@ -601,8 +627,20 @@ int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *
   const int64_t nt = (int64_t)(F / PK) * 256;
   proj_split_w_kernel<<<(unsigned)rk::ceil_div(nt, 256), 256, 0, st>>>(W, F, (char *)ws);
   RK_CHECK_LAUNCH("proj_split_w_kernel");
-  proj_fwd_tall_kernel<<<(unsigned)rk::ceil_div(n_items, PR), 320, 0, st>>>(X, n_items, F, (const char *)ws, b, Y + nu);
-  RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
+  const int parts = tall_fwd_parts(n_items, F);
+  const int32_t sps = (int32_t)rk::ceil_div(F / PK, parts);
+  const dim3 grid((unsigned)rk::ceil_div(n_items, PR), (unsigned)rk::ceil_div(F / PK, sps));
+  if (grid.y == 1) {
+    proj_fwd_tall_kernel<<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, Y + nu);
+    RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
+  } else {
+    float *slab = (float *)((char *)ws + (size_t)(F / PK) * PWB);
+    proj_fwd_tall_kernel<<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, slab);
+    RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
+    const int64_t n4 = (int64_t)n_items * 16;
+    proj_sum_parts_kernel<<<(unsigned)rk::ceil_div(n4, 256), 256, 0, st>>>(slab, (int32_t)grid.y, n4, b, Y + nu);
+    RK_CHECK_LAUNCH("proj_sum_parts_kernel");
+  }
   return RK_OK;
 }
 
