@@ -139,37 +139,47 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const float *__restrict__
 // builtin in front of the barrier is the synchronisation; M0 written one wait state ahead).
 constexpr int PR = 256;                 // rows of X per workgroup
 constexpr int PK = 32;                  // columns of X per stage
-constexpr int PST = 3;                  // stages in the ring
-constexpr int PXB = PR * PK * 4;        // bytes of X per stage (8 KB per wavefront)
-constexpr int PWB = 3 * 2 * 2 * 64 * 16;   // bytes of split weights per stage: [part][k16][half][col][8 bf16]
-constexpr int PNX = 8, PNW = 3;         // DMA instructions per wavefront and stage (X, W)
+constexpr int PXB = PR * PK * 4;        // bytes of X per stage (8 KB per computing wavefront)
+// D = 64: three stages of 32 + 12 KB; D = 128: two of 32 + 24 KB (three do not fit 160 KB)
+template <int D> struct TallFwd {
+  static constexpr int NCB = D / 32;                    // blocks of 32 output columns, all of them in every wavefront
+  static constexpr int WB = 3 * 2 * 2 * D * 16;         // bytes of split weights per stage: [part][k16][half][col][8 bf16]
+  static constexpr int PART = 2 * 2 * D * 16;           // bytes of one part of a stage
+  static constexpr int ST = D == 64 ? 3 : 2;            // stages in the ring
+  static constexpr int NX = PXB / 1024, NW = WB / 1024; // DMA instructions per stage
+};
 
+template <int D>
 __global__ __launch_bounds__(256) void proj_split_w_kernel(const float *__restrict__ W, int32_t F,
                                                            char *__restrict__ Wp) {
   // thread -> (stage c, k16 s, half h, column): eight consecutive k of one row of W
+  using T = TallFwd<D>;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = (int64_t)(F / PK) * 2 * 2 * 64;
+  const int64_t n = (int64_t)(F / PK) * 2 * 2 * D;
   if (t >= n) return;
-  const int col = (int)(t & 63), h = (int)((t >> 6) & 1), s2 = (int)((t >> 7) & 1);
-  const int64_t c = t >> 8;
+  const int col = (int)(t % D), h = (int)((t / D) & 1), s2 = (int)((t / (2 * D)) & 1);
+  const int64_t c = t / (4 * D);
   const float *src = W + (int64_t)col * F + c * PK + s2 * 16 + h * 8;
   const floatx4 v0 = *reinterpret_cast<const floatx4 *>(src), v1 = *reinterpret_cast<const floatx4 *>(src + 4);
   const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
   rk::SplitN<8> sp;
   rk::split3(x, sp);
-  char *dst = Wp + c * PWB + (size_t)((s2 * 2 + h) * 1024 + col * 16);
+  char *dst = Wp + c * T::WB + (size_t)((s2 * 2 + h) * (D * 16) + col * 16);
   *reinterpret_cast<rk::bf16x8 *>(dst) = sp.h[0];
-  *reinterpret_cast<rk::bf16x8 *>(dst + 4096) = sp.m[0];
-  *reinterpret_cast<rk::bf16x8 *>(dst + 8192) = sp.l[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + T::PART) = sp.m[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 2 * T::PART) = sp.l[0];
 }
 
+template <int D>
 __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restrict__ X, int32_t n_items, int32_t F,
                                                             const char *__restrict__ Wp, const float *__restrict__ b,
                                                             int32_t steps_per_split, float *__restrict__ Yitems) {
   // blockIdx.y: which part of the feature columns (stages st_lo ..) this workgroup reduces over.  With
   // one part the result goes to Yitems with the bias; with several, part y's partial sums go to
-  // Yitems + y * n_items * 64 (a slab in the workspace), and proj_sum_parts_kernel adds them in order.
-  __shared__ __attribute__((aligned(16))) char plds[PST * (PXB + PWB)];
+  // Yitems + y * n_items * D (a slab in the workspace), and proj_sum_parts_kernel adds them in order.
+  using T = TallFwd<D>;
+  constexpr int NCB = T::NCB, ST = T::ST, SB = PXB + T::WB;
+  __shared__ __attribute__((aligned(16))) char plds[ST * SB];
   const int tid = threadIdx.x, lane = tid % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int64_t row0 = (int64_t)blockIdx.x * PR;
@@ -184,9 +194,9 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
     // wavefronts never wait for an issue slot, and this one never does anything else.
     // Piece i of a stage: rows 8i .. 8i+7 of the workgroup's 256, eight 16-byte pieces each; LDS
     // position p of row r receives global piece p ^ ((r >> 1) & 7).
-    uint32_t voff[4 * PNX];
+    uint32_t voff[T::NX];
 #pragma unroll
-    for (int i = 0; i < 4 * PNX; ++i) {
+    for (int i = 0; i < T::NX; ++i) {
       const int r = 8 * i + lane / 8;
       int64_t g = row0 + r;
       g = g < n_items ? g : n_items - 1;      // rows past the end re-read the last row; they are not stored
@@ -195,57 +205,51 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)plds);
     const uint32_t woff = (uint32_t)(lane * 16);
     auto issue = [&](int st) {
-      const uint32_t buf = lds0 + (uint32_t)((st % PST) * (PXB + PWB));
+      const uint32_t buf = lds0 + (uint32_t)((st % ST) * SB);
       const char *xb = reinterpret_cast<const char *>(X + row0 * F + (int64_t)(st_lo + st) * PK);
-      const char *wb = Wp + (int64_t)(st_lo + st) * PWB;
+      const char *wb = Wp + (int64_t)(st_lo + st) * T::WB;
 #pragma unroll
-      for (int i = 0; i < 4 * PNW; ++i)
+      for (int i = 0; i < T::NW; ++i)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      : : "v"(woff + (uint32_t)(i * 1024)), "s"(wb), "s"(buf + (uint32_t)(PXB + i * 1024)) : "memory", "m0");
 #pragma unroll
-      for (int i = 0; i < 4 * PNX; ++i)
+      for (int i = 0; i < T::NX; ++i)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      : : "v"(voff[i]), "s"(xb), "s"(buf + (uint32_t)(i * 1024)) : "memory", "m0");
     };
-    constexpr int kPerStage = 4 * (PNX + PNW);     // 44 of the 63 operations the counter holds
-    issue(0);
-    if (n_steps > 1) issue(1);
+    // ST - 1 stages are requested ahead of the one being computed; the in-order counter holds 63
+    // operations (44 per stage at D = 64, 56 at D = 128)
+    constexpr int kPerStage = T::NX + T::NW;
+    static_assert(kPerStage <= 63, "a stage's DMAs fit the memory counter");
+    for (int s0 = 0; s0 < ST - 1 && s0 < n_steps; ++s0) issue(s0);
     for (int st = 0; st < n_steps; ++st) {
-      // stage st has landed: the only DMAs issued after it are those of stage st + 1
-      if (st + 1 < n_steps)
+      // stage st has landed: the only DMAs issued after it are those of stage st + 1 (three-stage ring)
+      if (ST == 3 && st + 1 < n_steps)
         __builtin_amdgcn_s_waitcnt(0x0F70 | (kPerStage & 15) | ((kPerStage >> 4) << 14));
       else
         __builtin_amdgcn_s_waitcnt(0x0F70);
       __builtin_amdgcn_s_barrier();      // stage st is there, and everybody is past stage st - 1, whose buffer comes next
-      if (st + 2 < n_steps) issue(st + 2);
+      if (st + ST - 1 < n_steps) issue(st + ST - 1);
     }
     return;
   }
 
   const int col = lane & 31, half = lane >> 5;
-  floatx16 acc[2][2];
+  floatx16 acc[2][NCB];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.0f;
 
   for (int st = 0; st < n_steps; ++st) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");       // (the tiles change behind the compiler's back)
-    const char *xs = plds + (st % PST) * (PXB + PWB) + wave * 8192;
-    const char *ws = plds + (st % PST) * (PXB + PWB) + PXB;
+    const char *xs = plds + (st % ST) * SB + wave * 8192;
+    const char *ws = plds + (st % ST) * SB + PXB;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      rk::SplitN<8> bw[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const char *p = ws + (s2 * 2 + half) * 1024 + (cb * 32 + col) * 16;
-        bw[cb].h[0] = *reinterpret_cast<const rk::bf16x8 *>(p);
-        bw[cb].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 4096);
-        bw[cb].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 8192);
-      }
       rk::SplitN<8> ax[2];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
@@ -255,14 +259,25 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
         const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         rk::split3(x, ax[rb]);
       }
-      rk::mfma_split3_2x2(ax[0], ax[1], bw[0], bw[1], acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+#pragma unroll
+      for (int cp = 0; cp < NCB; cp += 2) {      // two column blocks at a time: four accumulators in turn
+        rk::SplitN<8> bw[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const char *p = ws + (s2 * 2 + half) * (D * 16) + ((cp + c2) * 32 + col) * 16;
+          bw[c2].h[0] = *reinterpret_cast<const rk::bf16x8 *>(p);
+          bw[c2].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + T::PART);
+          bw[c2].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 2 * T::PART);
+        }
+        rk::mfma_split3_2x2(ax[0], ax[1], bw[0], bw[1], acc[0][cp], acc[0][cp + 1], acc[1][cp], acc[1][cp + 1]);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
   }
   // C layout: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * half
-  float *out = Yitems + (int64_t)blockIdx.y * n_items * 64;
+  float *out = Yitems + (int64_t)blockIdx.y * n_items * D;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < NCB; ++cb) {
     const int n = 32 * cb + col;
     const float bias = (b && gridDim.y == 1) ? b[n] : 0.0f;
 #pragma unroll
@@ -270,18 +285,18 @@ __global__ __launch_bounds__(320) void proj_fwd_tall_kernel(const float *__restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = row0 + 64 * wave + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < n_items) out[m * 64 + n] = acc[rb][cb][r] + bias;
+        if (m < n_items) out[m * D + n] = acc[rb][cb][r] + bias;
       }
   }
 }
 
 // Y = bias + part 0 + part 1 + ... (in this order), four columns per thread
 __global__ __launch_bounds__(256) void proj_sum_parts_kernel(const float *__restrict__ parts, int32_t n_parts, int64_t n4,
-                                                             const float *__restrict__ b, float *__restrict__ Y) {
+                                                             const float *__restrict__ b, int32_t D, float *__restrict__ Y) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   floatx4 v = {0.f, 0.f, 0.f, 0.f};
-  if (b) v = *reinterpret_cast<const floatx4 *>(b + (i * 4) % 64);
+  if (b) v = *reinterpret_cast<const floatx4 *>(b + (i * 4) % D);
   for (int32_t p = 0; p < n_parts; ++p) v += reinterpret_cast<const floatx4 *>(parts)[(int64_t)p * n4 + i];
   reinterpret_cast<floatx4 *>(Y)[i] = v;
 }
@@ -295,7 +310,8 @@ inline int tall_fwd_parts(int32_t n_items, int32_t F) {
   return (int)(parts < 1 ? 1 : parts);
 }
 
-inline bool tall_fwd_shape(int32_t F, int32_t D) { return D == 64 && F % PK == 0 && F >= 2 * PK; }
+inline bool tall_fwd_shape(int32_t F, int32_t D) { return (D == 64 || D == 128) && F % PK == 0 && F >= 2 * PK; }
+inline size_t tall_fwd_wbytes(int32_t F, int32_t D) { return (size_t)(F / PK) * (D == 64 ? TallFwd<64>::WB : TallFwd<128>::WB); }
 
 // dW partial: workgroup (f-tile, d-tile, slice) reduces items [i_lo, i_hi).
 // A[i = d][k = item] = dY[item][d], B[k = item][j = f] = X[item][f].
@@ -386,10 +402,10 @@ __global__ __launch_bounds__(256) void proj_dw_kernel(const float *__restrict__ 
 
 
 // ---------------------------------------------------------------------------------------------
-// dW = dY_items^T X in the same form: D = 64, the reduction over the items on the bf16 matrix pipe.
-// A workgroup owns all 64 rows of dW x FT feature columns (FT = 512 or 384: four wavefronts x NF
-// blocks of 32) and one slice of the items; a stage is 16 items x FT columns of X (32 or 24 KB by
-// LDS-DMA from a fifth, producer wavefront, as in the forward) plus the stage's 6 KB of dY, which is
+// dW = dY_items^T X in the same form (D = 64 or 128): the reduction over the items on the bf16 matrix pipe.
+// A workgroup owns all D rows of dW x FT feature columns (D = 64: FT = 512 or 384, four wavefronts x NF
+// blocks of 32; D = 128: FT = 256) and one slice of the items; a stage is 16 items x FT columns of X
+// (16 to 32 KB by LDS-DMA from a fifth, producer wavefront, as in the forward) plus the stage's 6 (12) KB of dY, which is
 // split ONCE per call into bf16 parts laid out in fragment order (proj_split_dy_kernel; items past
 // the end are zero there, so the rows of X re-read in their place add nothing).  X enters the MFMA
 // as the B operand, eight ITEMS per lane at one feature: eight 4-byte LDS reads per block of 32
@@ -397,37 +413,43 @@ __global__ __launch_bounds__(256) void proj_dw_kernel(const float *__restrict__ 
 // so that the two halves of a wavefront read different banks.  Per slice a 64 x F partial result;
 // the slices are summed in slice order (slab_reduce): deterministic, no float atomics.
 constexpr int QI = 16;                              // items per stage
-constexpr int QYB = 3 * 2 * 2 * 32 * 16;            // bytes of split dY per stage: [part][d block][half][d][8 items]
+constexpr int QST = 3;                              // stages in the ring
+// bytes of split dY per stage: [part][d block][half][d][8 items]
+constexpr int dy_stage_bytes(int D) { return 3 * (D / 32) * 2 * 32 * 16; }
 
+template <int D>
 __global__ __launch_bounds__(256) void proj_split_dy_kernel(const float *__restrict__ dY, int32_t n_items,
                                                             int64_t n_stages, char *__restrict__ Yp) {
   // thread -> (stage, d block, half, d): eight consecutive items at one column of dY
+  constexpr int NDB = D / 32, PART = NDB * 2 * 32 * 16;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_stages * 128) return;
-  const int d = (int)(t & 31), h = (int)((t >> 5) & 1), db = (int)((t >> 6) & 1);
-  const int64_t st = t >> 7;
+  if (t >= n_stages * (2 * D)) return;
+  const int d = (int)(t & 31), h = (int)((t >> 5) & 1), db = (int)((t >> 6) % NDB);
+  const int64_t st = t / (2 * D);
   float x[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t i = st * QI + 8 * h + j;
-    x[j] = i < n_items ? dY[i * 64 + 32 * db + d] : 0.0f;
+    x[j] = i < n_items ? dY[i * D + 32 * db + d] : 0.0f;
   }
   rk::SplitN<8> sp;
   rk::split3(x, sp);
-  char *dst = Yp + st * QYB + (size_t)((db * 2 + h) * 512 + d * 16);
+  char *dst = Yp + st * dy_stage_bytes(D) + (size_t)((db * 2 + h) * 512 + d * 16);
   *reinterpret_cast<rk::bf16x8 *>(dst) = sp.h[0];
-  *reinterpret_cast<rk::bf16x8 *>(dst + 2048) = sp.m[0];
-  *reinterpret_cast<rk::bf16x8 *>(dst + 4096) = sp.l[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + PART) = sp.m[0];
+  *reinterpret_cast<rk::bf16x8 *>(dst + 2 * PART) = sp.l[0];
 }
 
-template <int NF>
+template <int NDB, int NF>
 __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restrict__ X, int32_t n_items, int32_t F,
                                                            const char *__restrict__ Yp, int32_t stages_per_slice,
                                                            int64_t n_stages, float *__restrict__ slab) {
   constexpr int FT = 128 * NF;                       // feature columns per workgroup
   constexpr int XB = QI * FT * 4;                    // bytes of X per stage
+  constexpr int QYB = dy_stage_bytes(32 * NDB), YPART = NDB * 2 * 32 * 16;
   constexpr int NX = XB / 1024, NY = QYB / 1024;     // DMA instructions per stage
   constexpr int PPRW = FT / 4;                       // 16-byte pieces per row of a stage
+  constexpr int PST = QST;
   __shared__ __attribute__((aligned(16))) char qlds[PST * (XB + QYB)];
   const int tid = threadIdx.x, lane = tid % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
         }
       }
     };
-    constexpr int kPerStage = NX + NY;               // 38 or 30 of the 63 operations the counter holds
+    constexpr int kPerStage = NX + NY;               // 28 to 38 of the 63 operations the counter holds
     if (n_steps > 0) issue(0);
     if (n_steps > 1) issue(1);
     for (int st = 0; st < n_steps; ++st) {
@@ -491,9 +513,9 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
   }
 
   const int col = lane & 31, half = lane >> 5;
-  floatx16 acc[2][NF];
+  floatx16 acc[NDB][NF];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int fb = 0; fb < NF; ++fb)
 #pragma unroll
@@ -504,13 +526,13 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
     asm volatile("" ::: "memory");       // (the tiles change behind the compiler's back)
     const char *xs = qlds + (st % PST) * (XB + QYB);
     const char *ys = xs + XB;
-    rk::SplitN<8> ay[2], bx[NF];
+    rk::SplitN<8> ay[NDB], bx[NF];
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+    for (int db = 0; db < NDB; ++db) {
       const char *p = ys + (db * 2 + half) * 512 + col * 16;
       ay[db].h[0] = *reinterpret_cast<const rk::bf16x8 *>(p);
-      ay[db].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 2048);
-      ay[db].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 4096);
+      ay[db].m[0] = *reinterpret_cast<const rk::bf16x8 *>(p + YPART);
+      ay[db].l[0] = *reinterpret_cast<const rk::bf16x8 *>(p + 2 * YPART);
     }
 #pragma unroll
     for (int fb = 0; fb < NF; ++fb) {
@@ -522,22 +544,20 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
       rk::split3(x, bx[fb]);
     }
     // one MFMA of each accumulator in turn (per accumulator: mfma_split3's operations and order)
-#define RK_DW_TERM(PA, PB)                                                                                    \
-  _Pragma("unroll") for (int fb = 0; fb < NF; ++fb) {                                                          \
-    acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[0].PA[0], bx[fb].PB[0], acc[0][fb], 0, 0, 0);      \
-    acc[1][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[1].PA[0], bx[fb].PB[0], acc[1][fb], 0, 0, 0);      \
-  }
+#define RK_DW_TERM(PA, PB)                                                                                       \
+  _Pragma("unroll") for (int fb = 0; fb < NF; ++fb) _Pragma("unroll") for (int db = 0; db < NDB; ++db)            \
+    acc[db][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[db].PA[0], bx[fb].PB[0], acc[db][fb], 0, 0, 0);
     RK_DW_TERM(l, h) RK_DW_TERM(h, l) RK_DW_TERM(m, m) RK_DW_TERM(m, h) RK_DW_TERM(h, m) RK_DW_TERM(h, h)
 #undef RK_DW_TERM
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's tiles have been read before the next barrier frees them
   }
   // slab[slice][d][f]; C layout: column (f) = lane & 31, row (d) = (r & 3) + 8 * (r >> 2) + 4 * half
-  float *out = slab + (int64_t)blockIdx.y * 64 * F;
+  float *out = slab + (int64_t)blockIdx.y * (32 * NDB) * F;
 #pragma unroll
   for (int fb = 0; fb < NF; ++fb) {
     const int32_t f = f0 + wave * (32 * NF) + 32 * fb + col;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = 32 * db + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -548,6 +568,7 @@ __global__ __launch_bounds__(320) void proj_dw_tall_kernel(const float *__restri
 
 // feature columns per workgroup of the tall dW kernel for a shape (0: the plain kernel takes it)
 inline int tall_dw_ft(int32_t F, int32_t D) {
+  if (D == 128) return F % 256 == 0 ? 256 : 0;      // sixteen accumulator blocks of a 512-column tile do not fit the registers
   if (D != 64) return 0;
   return F % 512 == 0 ? 512 : (F % 384 == 0 ? 384 : 0);
 }
@@ -604,7 +625,7 @@ int rk_proj_fwd_f32(const float *X, int32_t n_items, int32_t F, const float *W, 
 size_t rk_proj_fwd_ws_bytes(int32_t n_items, int32_t F, int32_t D) {
   if (n_items <= 0 || F <= 0 || D <= 0 || !tall_fwd_shape(F, D)) return 0;
   const int parts = tall_fwd_parts(n_items, F);
-  return (size_t)(F / PK) * PWB + (parts > 1 ? (size_t)parts * n_items * 64 * sizeof(float) : 0);
+  return tall_fwd_wbytes(F, D) + (parts > 1 ? (size_t)parts * n_items * D * sizeof(float) : 0);
 }
 
 int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *W, const float *b,
@@ -624,21 +645,25 @@ int rk_proj_fwd_ws_f32(const float *X, int32_t n_items, int32_t F, const float *
     proj_fill_users_kernel<<<(unsigned)rk::ceil_div(nu / 4, 256), 256, 0, st>>>(b, D, nu / 4, Y);
     RK_CHECK_LAUNCH("proj_fill_users_kernel");
   }
-  const int64_t nt = (int64_t)(F / PK) * 256;
-  proj_split_w_kernel<<<(unsigned)rk::ceil_div(nt, 256), 256, 0, st>>>(W, F, (char *)ws);
+  const int64_t nt = (int64_t)(F / PK) * 4 * D;
+  if (D == 64)
+    proj_split_w_kernel<64><<<(unsigned)rk::ceil_div(nt, 256), 256, 0, st>>>(W, F, (char *)ws);
+  else
+    proj_split_w_kernel<128><<<(unsigned)rk::ceil_div(nt, 256), 256, 0, st>>>(W, F, (char *)ws);
   RK_CHECK_LAUNCH("proj_split_w_kernel");
   const int parts = tall_fwd_parts(n_items, F);
   const int32_t sps = (int32_t)rk::ceil_div(F / PK, parts);
   const dim3 grid((unsigned)rk::ceil_div(n_items, PR), (unsigned)rk::ceil_div(F / PK, sps));
-  if (grid.y == 1) {
-    proj_fwd_tall_kernel<<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, Y + nu);
-    RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
-  } else {
-    float *slab = (float *)((char *)ws + (size_t)(F / PK) * PWB);
-    proj_fwd_tall_kernel<<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, slab);
-    RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
-    const int64_t n4 = (int64_t)n_items * 16;
-    proj_sum_parts_kernel<<<(unsigned)rk::ceil_div(n4, 256), 256, 0, st>>>(slab, (int32_t)grid.y, n4, b, Y + nu);
+  float *slab = (float *)((char *)ws + tall_fwd_wbytes(F, D));
+  float *dst = grid.y == 1 ? Y + nu : slab;
+  if (D == 64)
+    proj_fwd_tall_kernel<64><<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, dst);
+  else
+    proj_fwd_tall_kernel<128><<<grid, 320, 0, st>>>(X, n_items, F, (const char *)ws, b, sps, dst);
+  RK_CHECK_LAUNCH("proj_fwd_tall_kernel");
+  if (grid.y > 1) {
+    const int64_t n4 = (int64_t)n_items * D / 4;
+    proj_sum_parts_kernel<<<(unsigned)rk::ceil_div(n4, 256), 256, 0, st>>>(slab, (int32_t)grid.y, n4, b, D, Y + nu);
     RK_CHECK_LAUNCH("proj_sum_parts_kernel");
   }
   return RK_OK;
@@ -650,7 +675,7 @@ size_t rk_proj_bwd_ws_bytes(int32_t n_items, int32_t n_users, int32_t F, int32_t
   const TallDw tp = tall_dw_plan(n_items, F, D);
   const int slices = tp.ft ? tp.slices : dw_slices(n_items, F, D);
   size_t slab = ((size_t)slices * D * F + rk::slab_tmp_floats(slices, (int64_t)D * F)) * sizeof(float);
-  if (tp.ft) slab = ((slab + 255) & ~(size_t)255) + (size_t)tp.n_stages * QYB;
+  if (tp.ft) slab = ((slab + 255) & ~(size_t)255) + (size_t)tp.n_stages * dy_stage_bytes(D);
   const int64_t nb = rk::ceil_div((int64_t)n_items + n_users, rk::kColsumRows);
   const size_t bias = ((size_t)nb * D + rk::slab_tmp_floats((int32_t)nb, D)) * sizeof(float);
   return slab > bias ? slab : bias;
@@ -673,14 +698,19 @@ int rk_proj_bwd_f32(const float *X, int32_t n_items, int32_t F, const float *dY,
     RK_CHECK_ARG((int64_t)QI * F * 4 < ((int64_t)1 << 32), "feature width too large");
     const size_t slab_bytes = ((size_t)slices * nW + rk::slab_tmp_floats(slices, nW)) * sizeof(float);
     char *yp = (char *)ws + ((slab_bytes + 255) & ~(size_t)255);
-    proj_split_dy_kernel<<<(unsigned)rk::ceil_div(tp.n_stages * 128, 256), 256, 0, st>>>(dY + (int64_t)n_users * D, n_items,
-                                                                                          tp.n_stages, yp);
+    const unsigned sgrid = (unsigned)rk::ceil_div(tp.n_stages * 2 * D, 256);
+    if (D == 64)
+      proj_split_dy_kernel<64><<<sgrid, 256, 0, st>>>(dY + (int64_t)n_users * D, n_items, tp.n_stages, yp);
+    else
+      proj_split_dy_kernel<128><<<sgrid, 256, 0, st>>>(dY + (int64_t)n_users * D, n_items, tp.n_stages, yp);
     RK_CHECK_LAUNCH("proj_split_dy_kernel");
     dim3 grid((unsigned)(F / tp.ft), (unsigned)slices);
-    if (tp.ft == 512)
-      proj_dw_tall_kernel<4><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
+    if (D == 128)
+      proj_dw_tall_kernel<4, 2><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
+    else if (tp.ft == 512)
+      proj_dw_tall_kernel<2, 4><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
     else
-      proj_dw_tall_kernel<3><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
+      proj_dw_tall_kernel<2, 3><<<grid, 320, 0, st>>>(X, n_items, F, yp, tp.stages_per_slice, tp.n_stages, slab);
     RK_CHECK_LAUNCH("proj_dw_tall_kernel");
     const int rc = rk::slab_reduce(slab, slices, nW, nW, slab + (size_t)slices * nW, dW, st);
     if (rc != RK_OK) return rc;

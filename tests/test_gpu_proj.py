@@ -19,7 +19,9 @@ DEV = "cuda:0"
                                       (3, 1, 64, 64), (0, 255, 96, 64), (5, 256, 64, 64), (2, 257, 160, 64), (9, 1500, 1024, 64),
                                       # the tall weight-gradient kernel: 384- and 512-column workgroups, one item, item counts
                                       # around a stage of 16, more stages than slices
-                                      (1, 1, 384, 64), (0, 15, 512, 64), (4, 16, 768, 64), (2, 17, 1536, 64), (3, 5000, 384, 64)])
+                                      (1, 1, 384, 64), (0, 15, 512, 64), (4, 16, 768, 64), (2, 17, 1536, 64), (3, 5000, 384, 64),
+                                      # the same kernels at 128 outputs (two-stage ring forward, 256-column gradient workgroups)
+                                      (4, 300, 512, 128), (0, 1, 256, 128), (2, 17, 768, 128), (3, 2000, 4096, 128), (1, 257, 64, 128)])
 def test_projection_forward_backward(U, I, F, D):
     rng = np.random.default_rng(F + D)
     X = rng.standard_normal((I, F)).astype(np.float32)
