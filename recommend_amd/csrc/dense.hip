@@ -684,17 +684,20 @@ constexpr int kJobsPerLaunch = 16;
 struct ReduceJobs {
   rk_dense_reduce_job job[kJobsPerLaunch];
 };
-__global__ __launch_bounds__(256) void dense_reduce_jobs_kernel(ReduceJobs jobs) {
-  __shared__ float red[16][17];
+__global__ __launch_bounds__(1024) void dense_reduce_jobs_kernel(ReduceJobs jobs) {
+  // 64 consecutive elements x 16 strides over the partials: a wavefront reads 256 contiguous bytes of a partial
+  // (the sums and their order per element are those of the 256-thread kernel above)
+  __shared__ float red[16][65];
   const rk_dense_reduce_job &jb = jobs.job[blockIdx.y];
-  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + el;
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + el;
   float total = 0.0f;
   for (int32_t sl = 0; sl < jb.n_slabs; ++sl) {      // uniform over the workgroup
     const float *__restrict__ slab = jb.slabs[sl];
     float s0 = 0.0f, s1 = 0.0f;
     if (i < NRED) {
       int32_t p = q;
+#pragma unroll 4      // eight loads in flight; the additions keep their order
       for (; p + 16 < jb.n_part; p += 32) {
         s0 += slab[(int64_t)p * PART + i];
         s1 += slab[(int64_t)(p + 16) * PART + i];
@@ -849,7 +852,7 @@ int rk_dense_reduce_jobs_d_f32(const rk_dense_reduce_job *jobs, int32_t n_jobs, 
     ReduceJobs args;
     memset(&args, 0, sizeof args);
     for (int32_t j = 0; j < nj; ++j) args.job[j] = jobs[j0 + j];
-    dense_reduce_jobs_kernel<<<dim3((NRED + 15) / 16, nj), 256, 0, st>>>(args);
+    dense_reduce_jobs_kernel<<<dim3((NRED + 63) / 64, nj), 1024, 0, st>>>(args);
     RK_CHECK_LAUNCH("dense_reduce_jobs_kernel");
   }
   return RK_OK;

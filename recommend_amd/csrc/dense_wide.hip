@@ -587,17 +587,20 @@ constexpr int kJobsPerLaunchW = 16;
 struct ReduceJobsW {
   rk_dense_reduce_job job[kJobsPerLaunchW];
 };
-__global__ __launch_bounds__(256) void dense128_reduce_jobs_kernel(ReduceJobsW jobs) {
-  __shared__ float red[16][17];
+__global__ __launch_bounds__(1024) void dense128_reduce_jobs_kernel(ReduceJobsW jobs) {
+  // 64 consecutive elements x 16 strides over the partials: a wavefront reads 256 contiguous bytes of a partial
+  // (the sums and their order per element are those of the 256-thread kernel above)
+  __shared__ float red[16][65];
   const rk_dense_reduce_job &jb = jobs.job[blockIdx.y];
-  const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + el;
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + el;
   float total = 0.0f;
   for (int32_t sl = 0; sl < jb.n_slabs; ++sl) {      // uniform over the workgroup
     const float *__restrict__ slab = jb.slabs[sl];
     float s0 = 0.0f, s1 = 0.0f;
     if (idx < NREDW) {
       int32_t p = q;
+#pragma unroll 4      // eight loads in flight; the additions keep their order
       for (; p + 16 < jb.n_part; p += 32) {
         s0 += slab[(int64_t)p * PARTW + idx];
         s1 += slab[(int64_t)(p + 16) * PARTW + idx];
@@ -681,7 +684,7 @@ int dense128_reduce_jobs(const rk_dense_reduce_job *jobs, int32_t n_jobs, hipStr
     ReduceJobsW args;
     memset(&args, 0, sizeof args);
     for (int32_t j = 0; j < nj; ++j) args.job[j] = jobs[j0 + j];
-    dense128_reduce_jobs_kernel<<<dim3((NREDW + 15) / 16, nj), 256, 0, st>>>(args);
+    dense128_reduce_jobs_kernel<<<dim3((NREDW + 63) / 64, nj), 1024, 0, st>>>(args);
     RK_CHECK_LAUNCH("dense128_reduce_jobs_kernel");
   }
   return RK_OK;
