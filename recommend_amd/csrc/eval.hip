@@ -663,8 +663,11 @@ int exact_topk(const float *Uemb, int32_t n_users, const float *Iemb, int32_t n_
 constexpr int kOpenCap = 1024;
 inline int open_positions(int32_t n_users) { return (int)std::min<int64_t>(kOpenCap, rk::ceil_div(n_users, UPB) * UPB); }
 inline int open_nsplit(int32_t n_items, int32_t K) {
+  // as many slices as the one-level merge takes, down to one tile per slice: the launch costs about
+  // 15 us + 7 us per tile of a slice (a lone wavefront per SIMD whose lists never leave their start-up),
+  // the merge 11 -> 20 us from 55 to 220 lists (19k x 7k: 63 -> 42 us for the pair)
   const int64_t tiles = rk::ceil_div(n_items, TI);
-  return (int)std::max<int64_t>(1, std::min<int64_t>(kHeadsMaxLists, tiles / 4));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(kHeadsMaxLists, tiles));
 }
 // floats + ints of the compacted launch: its partial lists
 inline size_t open_part_entries(int32_t n_users, int32_t n_items, int32_t K) {
