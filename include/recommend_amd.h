@@ -69,7 +69,7 @@ int rk_csr_from_coo_host(const int32_t *key_host, const int32_t *other_host,
                          int32_t *idx_host, int32_t *eid_host);
 
 /* Row binning for the SpMM kernels (see rk_spmm_plan below): rows with more
- * than long_thresh edges are cut into chunks of 2048 edges, one workgroup each;
+ * than long_thresh edges are cut into chunks of 512 edges, one workgroup each;
  * rows longer than one chunk get one partial-row slot per chunk.  First call
  * with the six array pointers NULL to get the counts, then with buffers of
  * n_chunks (x4), n_multi and n_multi+1 entries. */

@@ -133,7 +133,12 @@ __device__ __forceinline__ float4 load_through(const float4 *p) {
                      __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
 }
 
-constexpr int kChunk = 2048;  // edges per long-tier workgroup (matches rk_spmm_plan_host)
+// Edges per long-tier workgroup (rk_spmm_plan_host cuts the rows).  A chunk is a chain of dependent
+// gather rounds (its 16 groups take four edges at a time), and on a small graph the longest chunk IS
+// the hop: 2048 edges ran 20.3 / 24.4 / 42.9 / 83.3 us per hop at the Baby / Sports / Clothing / Elec
+// shapes, 512 edges 13.1 / 18.7 / 34.0 / 81.0, 256 edges 12.7 / 19.7 / 34.5 / 82.4, 128 edges
+// 14.1 / 21.7 / 36.6 / 101.7 (more partial rows to store and fold).
+constexpr int kChunk = 512;
 
 struct PlanArgs {
   int32_t long_thresh, n_chunks, n_multi;
