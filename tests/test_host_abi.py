@@ -88,12 +88,14 @@ def test_empty_graph_and_no_ratings():
 
 
 def test_spmm_plan_covers_long_rows():
-    ptr = np.array([0, 3, 3, 703, 708, 5008], np.int32)       # rows of 3, 0, 700, 5, 4300 edges
+    """Rows above the threshold are cut into chunks of 512 edges; a row of one chunk needs no partial
+    slot, a row of several gets one slot per chunk."""
+    ptr = np.array([0, 3, 3, 403, 408, 1608], np.int32)       # rows of 3, 0, 400, 5, 1200 edges
     pl = ops.spmm_plan_host(ptr, 64)
     assert (pl["n_chunks"], pl["n_multi"], pl["n_slots"]) == (4, 1, 3)
     np.testing.assert_array_equal(pl["chunk_row"], [2, 4, 4, 4])
-    np.testing.assert_array_equal(pl["chunk_begin"], [3, 708, 2756, 4804])
-    np.testing.assert_array_equal(pl["chunk_end"], [703, 2756, 4804, 5008])
+    np.testing.assert_array_equal(pl["chunk_begin"], [3, 408, 920, 1432])
+    np.testing.assert_array_equal(pl["chunk_end"], [403, 920, 1432, 1608])
     np.testing.assert_array_equal(pl["chunk_slot"], [-1, 0, 1, 2])
     np.testing.assert_array_equal(pl["multi_rows"], [4])
     np.testing.assert_array_equal(pl["multi_slot_ptr"], [0, 3])
