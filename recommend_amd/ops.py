@@ -87,7 +87,10 @@ class CsrMatrix:
     """One sparse operand on one device: CSR arrays, edge values and the row
     binning the SpMM kernels use.  `eid` maps CSR positions to COO edge ids."""
 
-    LONG_THRESH = 64
+    # Rows with more edges than this go to whole workgroups.  A 16-lane group walks its row four edges
+    # at a time, one dependent gather round after the other: at 64 the longest group-tier rows were what
+    # a hop waited for (hop at the Elec shape 81.5 us; 32: 78.3, 24: 77.9, 16: 78.1, 12: 83.2, 8: 105.9).
+    LONG_THRESH = 32
 
     def __init__(self, rowptr, idx, eid, device, n_cols=None):
         self.n_rows = int(rowptr.shape[0] - 1)
